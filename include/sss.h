@@ -1,0 +1,78 @@
+/* libsss -- C ABI of the MI355X-native session-similarity hot path.
+ *
+ * The reference (ZongyueQin/SessionSimilaritySearch) is pure Python; the path sits behind three
+ * Python call surfaces rather than an FFI:
+ *   (i)   emb = data_encoder(data)                       test_amazon_filterd.py:498,553
+ *         (UnifyPoolingGraphLevelEncoder.forward,        model/model.py:279-351)
+ *   (ii)  build_index(emb, metric) / index.search(x, k)  test_amazon_filterd.py:207-223,578
+ *         (faiss.IndexFlatIP / IndexFlatL2)
+ *   (iii) normalize(vec)                                 util_amazon_filtered.py:28-31
+ * The Python drop-ins in sessionsimilaritysearch_amd/ keep those names and call ONLY the entry
+ * points below (ctypes).  INTEGRATION.md shows the binding a maintainer of the reference adds.
+ *
+ * Conventions (every entry point):
+ *   - all buffers are CALLER-OWNED DEVICE pointers (tensor.data_ptr()); nothing is allocated
+ *     or freed here and there is no host synchronisation: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream);
+ *   - return 0 on success, -1 bad argument, -2 workspace too small, -3 HIP error;
+ *     sss_last_error() returns the thread-local message of the last failure;
+ *   - re-entrant per stream; no global state except the error string.
+ */
+#ifndef SSS_H
+#define SSS_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int sss_version(void);
+const char* sss_last_error(void);
+
+/* ---- (iii) normalize -- util_amazon_filtered.py:28-31 (rule 0) and fine_tune_ours.py:38-40
+ * (rule 1).  In place on fp32 [n, d] rows with row stride `ld` floats.
+ *   rule 0: x / sqrt(max(sum x^2, eps))      (reference eps = 1e-6)
+ *   rule 1: x / (sqrt(sum x^2) + eps)        (reference eps = 1e-4)
+ * If row_norm_max != NULL it receives max over rows of the POST-normalisation 2-norm
+ * (one float, atomically maximised; caller zeroes it) -- used by the index for its error bound. */
+int sss_normalize_rows(float* x, int64_t n, int d, int64_t ld, float eps, int rule, void* stream);
+
+/* max over rows of ||x_i||_2 -> *out (device float, caller zeroes). */
+int sss_row_norm_max(const float* x, int64_t n, int d, float* out, void* stream);
+
+/* ---- (ii) IndexFlatIP.search -- test_amazon_filterd.py:578 (also :61,661; fine_tune_ours.py:882).
+ * q [nq, d] fp32, corpus [n, d] fp32 (row-major, as IndexFlatIP.add stored it), d in {64,128,256},
+ * k <= 116.  Writes D_out [nq, k] fp32 (descending) and I_out [nq, k] int64 = row + id_offset,
+ * ordered by (score desc, id asc); missing results: I = -1, D = -FLT_MAX (faiss convention).
+ * Scores are the canonical ones of DESIGN.md (float64 sequential dot rounded to float32).
+ * status [nq] int32: 0 = proven exact, 1 = not proven (caller re-runs those queries through
+ * sss_ip_topk_exhaustive).  corpus_max_norm = max row 2-norm of the corpus (for the bound).
+ * metric: 0 = inner product, 1 = squared L2 (IndexFlatL2, test_amazon_filterd.py:215-217;
+ * D ascending). */
+size_t sss_ip_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k);
+int sss_ip_topk(const float* q, int64_t nq, const float* corpus, int64_t n, int d, int k,
+                int64_t id_offset, float corpus_max_norm, float* D_out, int64_t* I_out,
+                int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Exhaustive exact search for a (small) set of queries: qsel [nsel] int32 are the query rows of
+ * q to process; results are written to rows qsel[i] of D_out / I_out.  Any n, any d % 4 == 0,
+ * k <= 1024.  workspace: sss_ip_topk_exhaustive_workspace_bytes(nsel, n). */
+size_t sss_ip_topk_exhaustive_workspace_bytes(int64_t nsel, int64_t n);
+int sss_ip_topk_exhaustive(const float* q, const int32_t* qsel, int64_t nsel, const float* corpus,
+                           int64_t n, int d, int k, int64_t id_offset, int metric, float* D_out,
+                           int64_t* I_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- multi-GPU: merge per-shard results after the all-gather (no reference equivalent; the
+ * reference is single process).  D_in/I_in [shards, nq, k] -> D_out/I_out [nq, k]. */
+int sss_topk_merge(const float* D_in, const int64_t* I_in, int shards, int64_t nq, int k,
+                   float* D_out, int64_t* I_out, void* stream);
+
+/* ---- (i) encoder pieces.  NodeAsinEmbedding.forward -- model/NodeEmbedding.py:137-138:
+ * out[i, :] = table[ids[i], :]; out row stride ld_out floats (writes slice 0 of the node buffer). */
+int sss_gather_rows(const float* table, const int64_t* ids, int64_t n, int d, float* out,
+                    int64_t ld_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,32 @@
+"""Dev helper: time the fused scoring kernel on random unit vectors (not the official bench)."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sessionsimilaritysearch_amd.index import FlatIndex, normalize_
+
+def run(nq, n, d, k, iters=5):
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    c = torch.randn((n, d), device=dev, generator=g); normalize_(c)
+    q = torch.randn((nq, d), device=dev, generator=g); normalize_(q)
+    idx = FlatIndex(d, "ip", dev).adopt(c)
+    idx.corpus_max_norm()
+    out = idx.search_fused(q, k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        idx.search_fused(q, k, out)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * nq * n * d / (ms * 1e-3) / 1e12
+    bad = int(out[2].sum().item())
+    print(json.dumps(dict(nq=nq, n=n, d=d, k=k, ms=round(ms, 4), tflops=round(tf, 2), frac=round(tf / 157.3, 4),
+                          qps=round(nq / (ms * 1e-3)), unproven=bad)), flush=True)
+
+if __name__ == "__main__":
+    shapes = [(1024, 100_000, 128, 10), (1024, 1_000_000, 128, 10), (1024, 10_000_000, 128, 10),
+              (256, 1_000_000, 128, 10), (4096, 1_000_000, 128, 10), (1024, 1_000_000, 64, 10),
+              (1024, 1_000_000, 256, 10), (1024, 1_000_000, 128, 100)]
+    for s in shapes:
+        run(*s)

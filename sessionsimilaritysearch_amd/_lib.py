@@ -1,0 +1,92 @@
+"""ctypes binding of libsss.so (the C ABI declared in include/sss.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails, this
+module raises.  ``build()`` compiles the library in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsss.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/sss.h one to one
+_SIGNATURES = {
+    "sss_version": (c_int, []),
+    "sss_last_error": (ctypes.c_char_p, []),
+    "sss_normalize_rows": (c_int, [c_void_p, c_int64, c_int, c_int64, c_float, c_int, c_void_p]),
+    "sss_row_norm_max": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "sss_ip_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "sss_ip_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_float,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sss_ip_topk_exhaustive_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sss_ip_topk_exhaustive": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
+                                       c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                       c_void_p]),
+    "sss_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "sss_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libsss.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libsss.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+                "sessionsimilaritysearch_amd/csrc`). There is no CPU fallback.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+class SssError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().sss_last_error()
+        raise SssError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(t, name, dtype=None):
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise SssError(f"{name} must be a CUDA (HIP) tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise SssError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise SssError(f"{name} must be contiguous")
+    return t

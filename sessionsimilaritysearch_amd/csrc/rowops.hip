@@ -1,0 +1,137 @@
+// HBM-bound row kernels: L2-normalise, row-norm max, embedding-row gather (gfx950).
+//
+//   k_normalize_rows  <- `normalize` (reference util_amazon_filtered.py:28-31; the
+//                        ||v||+1e-4 variant of fine_tune_ours.py:38-40 is rule 1)
+//   k_gather_rows     <- NodeAsinEmbedding.forward (reference model/NodeEmbedding.py:137-138)
+// Each row is owned by a group of LPR lanes that move 16 bytes per lane per access (coalesced
+// 16 B x LPR segments); reductions are butterflies inside the lane group.
+#include "sss_common.h"
+
+namespace sss {
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_normalize_rows(float* __restrict__ x, long n, int d, long ld,
+                                                        float eps, int rule) {
+    const int sub = threadIdx.x % LPR;
+    const long rows_per_block = 256 / LPR;
+    const int nv = d / 4;
+    for (long row = (long)blockIdx.x * rows_per_block + threadIdx.x / LPR; row < n;
+         row += (long)gridDim.x * rows_per_block) {
+        float4* p = reinterpret_cast<float4*>(x + row * ld);
+        float ss = 0.f;
+        for (int i = sub; i < nv; i += LPR) {
+            const float4 v = p[i];
+            ss += v.x * v.x; ss += v.y * v.y; ss += v.z * v.z; ss += v.w * v.w;
+        }
+        ss = group_sum<LPR>(ss);
+        const float den = rule == 0 ? sqrtf(fmaxf(ss, eps)) : sqrtf(ss) + eps;
+        for (int i = sub; i < nv; i += LPR) {
+            float4 v = p[i];
+            v.x /= den; v.y /= den; v.z /= den; v.w /= den;
+            p[i] = v;
+        }
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_row_norm_max(const float* __restrict__ x, long n, int d,
+                                                      float* __restrict__ out) {
+    const int sub = threadIdx.x % LPR;
+    const long rows_per_block = 256 / LPR;
+    const int nv = d / 4;
+    float m = 0.f;
+    for (long row = (long)blockIdx.x * rows_per_block + threadIdx.x / LPR; row < n;
+         row += (long)gridDim.x * rows_per_block) {
+        const float4* p = reinterpret_cast<const float4*>(x + row * (long)d);
+        float ss = 0.f;
+        for (int i = sub; i < nv; i += LPR) {
+            const float4 v = p[i];
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        ss = group_sum<LPR>(ss);
+        m = fmaxf(m, ss);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(reinterpret_cast<unsigned int*>(out), __builtin_bit_cast(unsigned int, sqrtf(m) * 1.0000002f));
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ table,
+                                                     const long* __restrict__ ids, long n, int d,
+                                                     float* __restrict__ out, long ld_out) {
+    const int sub = threadIdx.x % LPR;
+    const long rows_per_block = 256 / LPR;
+    const int nv = d / 4;
+    for (long row = (long)blockIdx.x * rows_per_block + threadIdx.x / LPR; row < n;
+         row += (long)gridDim.x * rows_per_block) {
+        const float4* src = reinterpret_cast<const float4*>(table + ids[row] * (long)d);
+        float4* dst = reinterpret_cast<float4*>(out + row * ld_out);
+        for (int i = sub; i < nv; i += LPR) dst[i] = src[i];
+    }
+}
+
+static int lanes_per_row(int d) {
+    const int nv = d / 4;
+    int l = 1;
+    while (l < nv && l < 64) l <<= 1;
+    return l;
+}
+static unsigned grid_for(long n, int lpr) {
+    const long rpb = 256 / lpr;
+    long g = (n + rpb - 1) / rpb;
+    if (g > 256 * 8) g = 256 * 8;   // ~8 blocks per CU, grid-stride the rest
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
+#define SSS_DISPATCH_LPR(lpr, CALL) \
+    switch (lpr) {                  \
+        case 1: { constexpr int L = 1; CALL; } break;   \
+        case 2: { constexpr int L = 2; CALL; } break;   \
+        case 4: { constexpr int L = 4; CALL; } break;   \
+        case 8: { constexpr int L = 8; CALL; } break;   \
+        case 16: { constexpr int L = 16; CALL; } break; \
+        case 32: { constexpr int L = 32; CALL; } break; \
+        default: { constexpr int L = 64; CALL; } break; \
+    }
+
+int normalize_rows(float* x, long n, int d, long ld, float eps, int rule, hipStream_t st) {
+    if (n < 0 || d <= 0 || d % 4 || ld < d || ld % 4 || (rule != 0 && rule != 1)) {
+        set_error("normalize_rows: need n >= 0, d %% 4 == 0, ld >= d, ld %% 4 == 0, rule in {0,1}");
+        return SSS_EINVAL;
+    }
+    if (n == 0) return SSS_OK;
+    const int lpr = lanes_per_row(d);
+    SSS_DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_normalize_rows<L>, dim3(grid_for(n, L)), dim3(256), 0, st, x, n, d, ld, eps, rule));
+    return check_launch("k_normalize_rows");
+}
+
+int row_norm_max(const float* x, long n, int d, float* out, hipStream_t st) {
+    if (n < 0 || d <= 0 || d % 4) { set_error("row_norm_max: need n >= 0, d %% 4 == 0"); return SSS_EINVAL; }
+    if (n == 0) return SSS_OK;
+    const int lpr = lanes_per_row(d);
+    SSS_DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_row_norm_max<L>, dim3(grid_for(n, L)), dim3(256), 0, st, x, n, d, out));
+    return check_launch("k_row_norm_max");
+}
+
+int gather_rows(const float* table, const long* ids, long n, int d, float* out, long ld_out, hipStream_t st) {
+    if (n < 0 || d <= 0 || d % 4 || ld_out < d || ld_out % 4) {
+        set_error("gather_rows: need n >= 0, d %% 4 == 0, ld_out >= d, ld_out %% 4 == 0");
+        return SSS_EINVAL;
+    }
+    if (n == 0) return SSS_OK;
+    const int lpr = lanes_per_row(d);
+    SSS_DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_gather_rows<L>, dim3(grid_for(n, L)), dim3(256), 0, st, table, ids, n, d, out, ld_out));
+    return check_launch("k_gather_rows");
+}
+
+}  // namespace sss

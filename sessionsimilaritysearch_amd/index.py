@@ -1,0 +1,232 @@
+"""faiss-shaped flat index on one MI355X + the reference's ``build_index`` / ``normalize``.
+
+Drop-in surface (same names, argument meaning and error behaviour as the reference):
+
+* ``normalize(vec)``                  <- ``util_amazon_filtered.py:28-31``
+* ``build_index(emb, metric)``        <- ``test_amazon_filterd.py:207-223`` ('cos' | 'l2' | 'ip',
+                                         anything else raises ``RuntimeError("Unregnozed metric", metric)``)
+* ``FlatIndex(d).add(x)`` / ``.search(x, k) -> (D, I)`` / ``.ntotal`` / ``.d``
+                                      <- ``faiss.IndexFlatIP`` / ``IndexFlatL2`` as used at
+                                         ``test_amazon_filterd.py:212-220,578``
+
+All arithmetic runs in the HIP kernels of ``libsss.so``; torch only owns device memory and the
+stream.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+FUSED_DIMS = (64, 128, 256)
+FUSED_MAX_K = 116
+_EXHAUSTIVE_WS_BYTES = 1 << 30
+
+
+def _dev(device=None):
+    if not torch.cuda.is_available():
+        raise _lib.SssError("no HIP device available: the session-similarity path runs on MI355X only")
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+    if device.type != "cuda":
+        raise _lib.SssError(f"device must be a HIP device, got {device}")
+    return torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+
+
+def _as_device_f32(x, device):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    if not isinstance(x, torch.Tensor):
+        raise TypeError("expected a numpy array or torch tensor")
+    return x.to(device=device, dtype=torch.float32).contiguous()
+
+
+def normalize_(x: torch.Tensor, eps: float = 1e-6, rule: int = 0) -> torch.Tensor:
+    """In-place row normalisation of a CUDA float32 [n, d] tensor (rows may be strided)."""
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32 or not x.is_cuda:
+        raise _lib.SssError("normalize_: need a CUDA float32 [n, d] tensor with unit inner stride")
+    rc = _lib.lib().sss_normalize_rows(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), eps, rule,
+                                       _lib.stream_ptr(x.device))
+    _lib.check(rc, "sss_normalize_rows")
+    return x
+
+
+def normalize(vec, eps: float = 1e-6, rule: int = 0):
+    """Reference ``normalize``: ``v / sqrt(clip(sum(v**2), 1e-6))`` row-wise (1-D input: the
+    whole vector).  numpy in -> numpy out; CUDA tensor in -> new CUDA tensor out.
+    ``rule=1, eps=1e-4`` gives the fine-tune scripts' ``v / (||v|| + 1e-4)``."""
+    is_np = isinstance(vec, np.ndarray)
+    dev = _dev() if is_np or not vec.is_cuda else vec.device
+    one_d = vec.ndim == 1
+    x = _as_device_f32(vec, dev)
+    if x.data_ptr() == (vec.data_ptr() if isinstance(vec, torch.Tensor) else 0):
+        x = x.clone()
+    if one_d:
+        x = x.view(1, -1)
+    d = x.shape[1]
+    if d % 4:                       # kernel moves 16 bytes per lane: pad the row, cut it back
+        pad = torch.zeros(x.shape[0], (d + 3) // 4 * 4, device=dev, dtype=torch.float32)
+        pad[:, :d] = x
+        x = normalize_(pad, eps, rule)[:, :d].contiguous()
+    else:
+        normalize_(x, eps, rule)
+    if one_d:
+        x = x.view(-1)
+    return x.cpu().numpy() if is_np else x
+
+
+class FlatIndex:
+    """Exact flat index (faiss ``IndexFlatIP`` / ``IndexFlatL2`` semantics) with
+    the canonical result contract of DESIGN.md: scores are float64-accumulated dot products
+    rounded to float32, ordered by (score desc, id asc); missing results are (-FLT_MAX, -1)."""
+
+    def __init__(self, d: int, metric: str = "ip", device=None):
+        if metric not in ("ip", "l2"):
+            raise ValueError("metric must be 'ip' or 'l2'")
+        self.d = int(d)
+        self.metric = metric
+        self.device = _dev(device)
+        self._xb = torch.empty((0, self.d), dtype=torch.float32, device=self.device)
+        self._cmax_t = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._cmax = None
+        self._ws = None
+        self.id_offset = 0              # global id of row 0 (row-sharded corpora)
+        self.last_fallback_queries = 0  # queries of the last search() re-run exhaustively
+
+    @property
+    def ntotal(self) -> int:
+        return int(self._xb.shape[0])
+
+    def add(self, x):
+        """Append rows (copied, ids = insertion order) -- ``IndexFlatIP.add``."""
+        x = _as_device_f32(x, self.device)
+        if x.dim() != 2 or x.shape[1] != self.d:
+            raise ValueError(f"add: expected [n, {self.d}], got {tuple(x.shape)}")
+        self._xb = x.clone() if self._xb.shape[0] == 0 else torch.cat([self._xb, x], dim=0)
+        if self.d % 4 == 0 and x.shape[0]:
+            rc = _lib.lib().sss_row_norm_max(x.data_ptr(), x.shape[0], self.d, self._cmax_t.data_ptr(),
+                                             _lib.stream_ptr(self.device))
+            _lib.check(rc, "sss_row_norm_max")
+        self._cmax = None
+
+    def adopt(self, xb: torch.Tensor, id_offset: int = 0):
+        """Use an existing CUDA float32 [n, d] tensor as the corpus without copying it."""
+        _lib.require_cuda(xb, "xb", torch.float32)
+        if xb.dim() != 2 or xb.shape[1] != self.d:
+            raise ValueError("adopt: wrong shape")
+        self._xb = xb
+        self.id_offset = int(id_offset)
+        self._cmax_t.zero_()
+        rc = _lib.lib().sss_row_norm_max(xb.data_ptr(), xb.shape[0], self.d, self._cmax_t.data_ptr(),
+                                         _lib.stream_ptr(self.device))
+        _lib.check(rc, "sss_row_norm_max")
+        self._cmax = None
+        return self
+
+    def corpus_max_norm(self) -> float:
+        if self._cmax is None:
+            self._cmax = float(self._cmax_t.item())
+        return self._cmax
+
+    # ------------------------------------------------------------------ device-level search
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def fused_ok(self, k: int) -> bool:
+        return self.metric == "ip" and self.d in FUSED_DIMS and 0 < k <= FUSED_MAX_K and self.ntotal > 0
+
+    def search_fused(self, q: torch.Tensor, k: int, out=None):
+        """Enqueue the fused MFMA scoring + top-k on the current stream; no host sync.
+        Returns (D [nq,k] f32, I [nq,k] i64, status [nq] i32) CUDA tensors; rows with
+        status != 0 must be re-run with ``search_exhaustive`` (``search`` does that)."""
+        L = _lib.lib()
+        _lib.require_cuda(q, "q", torch.float32)
+        nq, n = q.shape[0], self.ntotal
+        if out is None:
+            D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+            status = torch.empty((nq,), dtype=torch.int32, device=self.device)
+        else:
+            D, I, status = out
+        nbytes = L.sss_ip_topk_workspace_bytes(nq, n, self.d, k)
+        ws = self._workspace(nbytes)
+        rc = L.sss_ip_topk(q.data_ptr(), nq, self._xb.data_ptr(), n, self.d, k, self.id_offset,
+                           self.corpus_max_norm(), D.data_ptr(), I.data_ptr(), status.data_ptr(),
+                           ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
+        _lib.check(rc, "sss_ip_topk")
+        return D, I, status
+
+    def search_exhaustive(self, q: torch.Tensor, k: int, D: torch.Tensor, I: torch.Tensor, rows=None):
+        """Exhaustive exact path for query rows ``rows`` (all when None); writes into D / I."""
+        L = _lib.lib()
+        n = self.ntotal
+        if rows is None:
+            rows = torch.arange(q.shape[0], dtype=torch.int32, device=self.device)
+        rows = rows.to(device=self.device, dtype=torch.int32).contiguous()
+        per = max(1, min(65535, _EXHAUSTIVE_WS_BYTES // max(1, 4 * n)))
+        metric = 0 if self.metric == "ip" else 1
+        for lo in range(0, rows.numel(), per):
+            sel = rows[lo:lo + per].contiguous()
+            nbytes = L.sss_ip_topk_exhaustive_workspace_bytes(sel.numel(), n)
+            ws = self._workspace(nbytes)
+            rc = L.sss_ip_topk_exhaustive(q.data_ptr(), sel.data_ptr(), sel.numel(), self._xb.data_ptr(), n,
+                                          self.d, k, self.id_offset, metric, D.data_ptr(), I.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
+            _lib.check(rc, "sss_ip_topk_exhaustive")
+
+    def search_device(self, q: torch.Tensor, k: int):
+        """Exact search, CUDA tensors in and out (syncs once to read the status vector)."""
+        nq = q.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        self.last_fallback_queries = 0
+        if nq == 0:
+            return D, I
+        if self.ntotal == 0:
+            D.fill_(-3.4028234663852886e38 if self.metric == "ip" else 3.4028234663852886e38)
+            I.fill_(-1)
+            return D, I
+        if self.d % 4:
+            raise _lib.SssError("d must be a multiple of 4")
+        if self.fused_ok(k):
+            status = torch.empty((nq,), dtype=torch.int32, device=self.device)
+            self.search_fused(q, k, (D, I, status))
+            bad = torch.nonzero(status).flatten()
+            if bad.numel():
+                self.last_fallback_queries = int(bad.numel())
+                self.search_exhaustive(q, k, D, I, bad)
+        else:
+            self.last_fallback_queries = nq
+            self.search_exhaustive(q, k, D, I)
+        return D, I
+
+    def search(self, x, k: int):
+        """``index.search(x, k) -> (D, I)``: numpy in -> numpy out (faiss), tensor in -> tensors."""
+        is_np = isinstance(x, np.ndarray)
+        q = _as_device_f32(x, self.device)
+        if q.dim() != 2 or q.shape[1] != self.d:
+            raise ValueError(f"search: expected [nq, {self.d}], got {tuple(q.shape)}")
+        D, I = self.search_device(q, int(k))
+        if is_np:
+            return D.cpu().numpy(), I.cpu().numpy()
+        return D, I
+
+
+def build_index(emb, metric: str, device=None) -> FlatIndex:
+    """Reference ``build_index(emb, metric)`` (test_amazon_filterd.py:207-223)."""
+    if metric == "cos":
+        index = FlatIndex(emb.shape[1], "ip", device)
+        index.add(normalize(emb))
+    elif metric == "l2":
+        index = FlatIndex(emb.shape[1], "l2", device)
+        index.add(emb)
+    elif metric == "ip":
+        index = FlatIndex(emb.shape[1], "ip", device)
+        index.add(emb)
+    else:
+        raise RuntimeError("Unregnozed metric", metric)
+    return index

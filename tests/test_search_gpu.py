@@ -1,0 +1,193 @@
+"""GPU parity: fused MFMA scoring + top-k (libsss, through the C ABI) vs the CPU oracle.
+
+Bar (BASELINE.json north_star): top-k indices bit-exact, scores within 1e-5 -- the canonical
+contract makes the scores bit-exact too, so both are compared with ``array_equal``.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import search_ref as sr
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return sr.normalize(x).astype(np.float32)
+
+
+def _index(c, cuda, metric="ip"):
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    idx = FlatIndex(c.shape[1], metric, cuda)
+    idx.add(c)
+    return idx
+
+
+@pytest.mark.parametrize("nq,n,d,k", [
+    (64, 20000, 128, 10),      # the headline shape, small
+    (1000, 1000, 64, 10),      # config C1: all-vs-all, d=64
+    (300, 5000, 128, 10),      # nq not a multiple of 32/256
+    (33, 777, 128, 10),        # ragged everything
+    (256, 4096, 256, 10),      # d=256
+    (128, 30000, 128, 100),    # reference K=100 (test_amazon_filterd.py:459)
+    (17, 100, 128, 16),        # k == list length
+    (5, 64, 128, 1),
+])
+def test_fused_matches_oracle(cuda, nq, n, d, k):
+    rng = np.random.default_rng(nq * 7919 + n)
+    q, c = _unit(rng, nq, d), _unit(rng, n, d)
+    idx = _index(c, cuda)
+    D, I = idx.search(q, k)
+    Dr, Ir = sr.search_exact(q, c, k)
+    assert np.array_equal(I, Ir)
+    assert np.array_equal(D, Dr)
+    assert np.abs(D - Dr).max() <= 1e-5
+
+
+def test_random_data_is_proven_exact_without_fallback(cuda):
+    rng = np.random.default_rng(5)
+    q, c = _unit(rng, 512, 128), _unit(rng, 100000, 128)
+    idx = _index(c, cuda)
+    D, I = idx.search(q, 10)
+    assert idx.last_fallback_queries == 0
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_duplicates_tie_break_by_id(cuda):
+    """Exact duplicates tie exactly; the contract orders them by ascending id."""
+    rng = np.random.default_rng(11)
+    base = _unit(rng, 50, 128)
+    c = np.repeat(base, 40, axis=0)            # 2000 rows, 40 copies each
+    perm = rng.permutation(c.shape[0])
+    c = c[perm]
+    q = _unit(rng, 40, 128)
+    idx = _index(c, cuda)
+    D, I = idx.search(q, 10)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_all_identical_rows(cuda):
+    c = np.tile(_unit(np.random.default_rng(1), 1, 128), (3000, 1))
+    q = _unit(np.random.default_rng(2), 9, 128)
+    idx = _index(c, cuda)
+    D, I = idx.search(q, 10)
+    assert np.array_equal(I, np.tile(np.arange(10), (9, 1)))
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(D, Dr)
+
+
+def test_sorted_adversarial_corpus(cuda):
+    """Rows ordered by ascending score for query 0: every row beats the running threshold."""
+    rng = np.random.default_rng(3)
+    q = _unit(rng, 4, 128)
+    c = _unit(rng, 20000, 128)
+    order = np.argsort(c @ q[0])
+    c = np.ascontiguousarray(c[order])
+    idx = _index(c, cuda)
+    D, I = idx.search(q, 10)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_fewer_rows_than_k_pads_like_faiss(cuda):
+    rng = np.random.default_rng(4)
+    q, c = _unit(rng, 6, 128), _unit(rng, 7, 128)
+    idx = _index(c, cuda)
+    D, I = idx.search(q, 10)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    assert (I[:, 7:] == -1).all() and (D[:, 7:] == sr.NEG_SENTINEL).all()
+
+
+def test_small_corpus_large_k_uses_exhaustive_and_is_exact(cuda):
+    rng = np.random.default_rng(6)
+    q, c = _unit(rng, 12, 128), _unit(rng, 90, 128)
+    idx = _index(c, cuda)
+    D, I = idx.search(q, 100)
+    Dr, Ir = sr.search_exact(q, c, 100)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_reference_dim_1600_goes_through_exhaustive(cuda):
+    """The reference's session vectors are D=1600 (pretrain_filtered_amazon.py:281)."""
+    rng = np.random.default_rng(8)
+    q, c = _unit(rng, 8, 1600), _unit(rng, 3000, 1600)
+    idx = _index(c, cuda)
+    D, I = idx.search(q, 100)
+    Dr, Ir = sr.search_exact(q, c, 100)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_l2_metric(cuda):
+    rng = np.random.default_rng(9)
+    q = rng.standard_normal((10, 128)).astype(np.float32)
+    c = rng.standard_normal((2000, 128)).astype(np.float32)
+    from sessionsimilaritysearch_amd.index import build_index
+    idx = build_index(c, "l2", cuda)
+    D, I = idx.search(q, 10)
+    Dr, Ir = sr.build_index(c, "l2").search(q, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_build_index_metrics_and_error(cuda):
+    from sessionsimilaritysearch_amd.index import build_index
+    rng = np.random.default_rng(10)
+    emb = rng.standard_normal((500, 128)).astype(np.float32) * 3
+    q = rng.standard_normal((20, 128)).astype(np.float32)
+    for metric in ("cos", "ip"):
+        idx = build_index(emb, metric, cuda)
+        ref = sr.build_index(emb, metric)
+        if metric == "cos":
+            # feed the oracle index the GPU-normalised rows so ids are comparable bit for bit
+            ref = sr.FlatIndexRef(128, "ip"); ref.add(idx._xb.cpu().numpy())
+        D, I = idx.search(q, 10)
+        Dr, Ir = ref.search(q, 10)
+        assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    with pytest.raises(RuntimeError):
+        build_index(emb, "hamming", cuda)
+
+
+def test_normalize_matches_reference_rule(cuda):
+    from sessionsimilaritysearch_amd.index import normalize
+    assert np.array_equal(normalize(np.ones(4, np.float32)), np.full(4, 0.5, np.float32))  # test_amazon_filterd.py:866
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal((1000, 128)) * rng.uniform(0.01, 10, (1000, 1))).astype(np.float32)
+    x[7] = 0.0                                   # all-zero row: stays zero, no NaN
+    x[8] = 1e-5                                  # below the clip
+    got, ref = normalize(x), sr.normalize(x)
+    assert np.isfinite(got).all() and (got[7] == 0).all()
+    np.testing.assert_allclose(got, ref, rtol=3e-7, atol=1e-9)
+    y = rng.standard_normal((33, 1600)).astype(np.float32)
+    np.testing.assert_allclose(normalize(y), sr.normalize(y), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(normalize(x, eps=1e-4, rule=1), sr.normalize_norm_eps(x), rtol=1e-6, atol=1e-9)
+    # idempotence (size-independent property) -- for rows whose norm is above the clip
+    keep = np.ones(1000, bool); keep[[7, 8]] = False
+    np.testing.assert_allclose(normalize(got[keep]), got[keep], rtol=3e-7, atol=1e-9)
+
+
+def test_shard_merge_equals_single_index(cuda):
+    """Row-sharding invariant: merged per-shard top-k == unsharded top-k."""
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    from sessionsimilaritysearch_amd import _lib
+    rng = np.random.default_rng(13)
+    q, c = _unit(rng, 100, 128), _unit(rng, 40000, 128)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    tq = torch.from_numpy(q).to(cuda)
+    for shards in (2, 4, 8):
+        per = c.shape[0] // shards
+        Ds, Is = [], []
+        for s in range(shards):
+            idx = FlatIndex(128, "ip", cuda)
+            idx.add(c[s * per:(s + 1) * per])
+            idx.id_offset = s * per
+            D, I = idx.search_device(tq, 10)
+            Ds.append(D); Is.append(I)
+        Din, Iin = torch.stack(Ds).contiguous(), torch.stack(Is).contiguous()
+        Dm = torch.empty_like(Ds[0]); Im = torch.empty_like(Is[0])
+        rc = _lib.lib().sss_topk_merge(Din.data_ptr(), Iin.data_ptr(), shards, 100, 10, Dm.data_ptr(),
+                                       Im.data_ptr(), _lib.stream_ptr(cuda))
+        _lib.check(rc, "merge")
+        assert np.array_equal(Im.cpu().numpy(), Ir) and np.array_equal(Dm.cpu().numpy(), Dr)
