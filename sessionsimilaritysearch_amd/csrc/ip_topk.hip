@@ -91,6 +91,8 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
     int li[KP];
 #pragma unroll
     for (int i = 0; i < KP; ++i) { ls[i] = -INFINITY; li[i] = -1; }
+    float pend_s = -INFINITY;   // one parked candidate per lane (see the epilogue)
+    int pend_i = -1;
 
     const long row_lo = (long)split * rows_per_split;
     long row_hi = row_lo + rows_per_split;
@@ -133,11 +135,16 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
 
         const char* tile = smem + buf * TILE_BYTES;
         f32x16 acc0 = {0}, acc1 = {0};
+        auto lda = [&](int u, int mb) -> float4 {
+            const int c = (2 * u) ^ x;                          // == (2u + h) ^ (r & 15)
+            return *reinterpret_cast<const float4*>(tile + ((r + 32 * mb) * CH + c) * 16);
+        };
+        float4 a0 = lda(0, 0), a1 = lda(0, 1);
 #pragma unroll
         for (int u = 0; u < D / 8; ++u) {
-            const int c = (2 * u) ^ x;                          // == (2u + h) ^ (r & 15)
-            const float4 a0 = *reinterpret_cast<const float4*>(tile + (r * CH + c) * 16);
-            const float4 a1 = *reinterpret_cast<const float4*>(tile + ((r + 32) * CH + c) * 16);
+            float4 n0 = a0, n1 = a1;
+            if (u + 1 < D / 8) { n0 = lda(u + 1, 0); n1 = lda(u + 1, 1); }   // one k-group ahead
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE this group's MFMAs
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, qreg[4 * u + 0], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, qreg[4 * u + 0], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, qreg[4 * u + 1], acc0, 0, 0, 0);
@@ -146,6 +153,8 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, qreg[4 * u + 2], acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, qreg[4 * u + 3], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, qreg[4 * u + 3], acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0; a1 = n1;
         }
 
         // ---- fused top-k epilogue.  acc[j] is (corpus row base + (j&3) + 8*(j>>2) + 4h, query r)
@@ -165,10 +174,22 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
             for (int j = 3; j < 15; j += 2) m = fmaxf(fmaxf(m, a[j]), a[j + 1]);
             m = fmaxf(m, a[15]);
             if (__builtin_amdgcn_ballot_w64(m > ls[KP - 1]) != 0) {
+                // A passing score parks in the lane's one pending slot; the 80-instruction
+                // sorted insert runs only when some lane needs its slot again (then every
+                // lane's pending entry goes in with that same pass).  ls[KP-1] may therefore
+                // lag behind -- it only admits extra candidates, never drops one.
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    if (__builtin_amdgcn_ballot_w64(a[j] > ls[KP - 1]) != 0)
-                        list_insert<KP>(ls, li, a[j], base + (j & 3) + 8 * (j >> 2));
+                    const bool pass = a[j] > ls[KP - 1];
+                    if (__builtin_amdgcn_ballot_w64(pass) != 0) {
+                        if (__builtin_amdgcn_ballot_w64(pass && pend_i >= 0) != 0) {
+                            list_insert<KP>(ls, li, pend_s, pend_i);
+                            pend_s = -INFINITY; pend_i = -1;
+                        }
+                        const bool still = a[j] > ls[KP - 1];
+                        pend_s = still ? a[j] : pend_s;
+                        pend_i = still ? base + (j & 3) + 8 * (j >> 2) : pend_i;
+                    }
                 }
             }
         }
@@ -176,6 +197,7 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
         __syncthreads();                                   // ... everyone's did, and this buffer is free
     }
 
+    list_insert<KP>(ls, li, pend_s, pend_i);   // no-op for lanes with an empty slot (-inf)
     // ---- spill the lane lists: cand[q][split*2 + h][KP]
     if (q_glob < nq) {
         const size_t o = ((size_t)q_glob * (2 * S) + (size_t)split * 2 + h) * KP;
