@@ -46,10 +46,14 @@ __device__ __forceinline__ void list_insert(float (&ls)[N], int (&li)[N], float 
     }
 }
 
-template <int D>
+// PRE = true is the sampled pre-pass: same MFMA stream, but the epilogue only keeps each lane's
+// running maximum; the K2-th largest of a query's 2*S lane maxima (k_tau) is a score that at
+// least K2 distinct corpus rows reach, i.e. a valid admission threshold for the main pass.
+template <int D, bool PRE>
 __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
-    const float* __restrict__ Q, int nq, const float* __restrict__ C, int n, int rows_per_split,
-    int S, int G, float* __restrict__ cand_s, int* __restrict__ cand_i) {
+    const float* __restrict__ Q, int nq, const float* __restrict__ C, int n, int tiles_per_split,
+    int total_tiles, int tile_step_rows, int S, int G, const float* __restrict__ tau0,
+    float* __restrict__ cand_s, int* __restrict__ cand_i) {
     constexpr int CH = D / 4;                       // 16-byte chunks per row
     constexpr int TILE_BYTES = TILE_ROWS * D * 4;
     constexpr int LOADS_PER_WAVE = CH / 8;          // glds wave-instructions per wave per tile
@@ -59,6 +63,10 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    // Waves 4-7 are the SIMD partners of waves 0-3.  They run their top-k epilogue one tile
+    // LATE (after the barrier, under the partner's first MFMAs of the next tile) so the two
+    // waves of a SIMD are never both outside their MFMA stream at a tile boundary.
+    const bool late = wave >= 4;                    // wave-uniform (scalar branch)
 
     // XCD-aware remap: blocks b and b+8 share an XCD (and its L2); the G query groups that
     // stream the same corpus split are given consecutive slots of ONE XCD so the split is
@@ -73,6 +81,7 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
     const int q_glob = g * WG_QUERIES + q_local;
     const int q_ld = q_glob < nq ? q_glob : nq - 1;
     float qreg[D / 2];
+    float t0 = -INFINITY;
     {
         const float4* qp = reinterpret_cast<const float4*>(Q + (size_t)q_ld * D) + h;
 #pragma unroll
@@ -81,30 +90,36 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
             qreg[4 * u + 0] = v.x; qreg[4 * u + 1] = v.y;
             qreg[4 * u + 2] = v.z; qreg[4 * u + 3] = v.w;
         }
+        if (tau0) t0 = tau0[q_ld];
         // retire the query loads HERE: otherwise hipcc sinks their counted vmcnt waits into the
         // tile loop, where they would also wait on the (uncounted) LDS-DMA of the next tile.
 #pragma unroll
         for (int t = 0; t < D / 2; ++t) asm volatile("" : "+v"(qreg[t]));
+        asm volatile("" : "+v"(t0));
     }
 
+    // Lane list, sorted descending.  Empty slots are (t0, -1): t0 is the admission threshold
+    // handed in by the sampled pre-pass (-inf without one), so "beats the list tail" is the only
+    // test the hot path needs.
     float ls[KP];
     int li[KP];
 #pragma unroll
-    for (int i = 0; i < KP; ++i) { ls[i] = -INFINITY; li[i] = -1; }
+    for (int i = 0; i < KP; ++i) { ls[i] = t0; li[i] = -1; }
     float pend_s = -INFINITY;   // one parked candidate per lane (see the epilogue)
     int pend_i = -1;
 
-    const long row_lo = (long)split * rows_per_split;
-    long row_hi = row_lo + rows_per_split;
-    if (row_hi > n) row_hi = n;
-    const int ntiles = row_lo < row_hi ? (int)((row_hi - row_lo + TILE_ROWS - 1) / TILE_ROWS) : 0;
+    int tile_lo = split * tiles_per_split;
+    int tile_hi = tile_lo + tiles_per_split;
+    if (tile_hi > total_tiles) tile_hi = total_tiles;
+    const int ntiles = tile_lo < tile_hi ? tile_hi - tile_lo : 0;
 
     // LDS-DMA staging (global_load_lds_dwordx4, 1 KiB per wave-instruction).  Written as inline
     // asm so hipcc neither counts it nor drains vmcnt(0) at the next ds_read: the next tile
     // stays in flight under this tile's MFMAs and is retired by the explicit vmcnt(0) that
     // precedes the barrier at the end of the iteration (cdna_hip_programming.md section 5.7).
     const unsigned lds_base = (unsigned)(unsigned long)(lptr_c)smem;
-    auto stage = [&](int buf, long row0) {
+    auto stage = [&](int buf, int tile_idx) {
+        const long row0 = (long)tile_idx * tile_step_rows;
 #pragma unroll
         for (int i = 0; i < LOADS_PER_WAVE; ++i) {
             const int instr = wave * LOADS_PER_WAVE + i;      // wave-uniform
@@ -124,22 +139,17 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
 
     // per-lane LDS read offset (bytes) of chunk (2u + h) of row r, before the constant part
     const int x = h ^ (r & 15);
+    f32x16 acc0 = {0}, acc1 = {0};
 
-    if (ntiles > 0) stage(0, row_lo);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) stage(buf ^ 1, row_lo + (long)(t + 1) * TILE_ROWS);
-
+    auto mfma_tile = [&](int buf, int next_tile) {
         const char* tile = smem + buf * TILE_BYTES;
-        f32x16 acc0 = {0}, acc1 = {0};
         auto lda = [&](int u, int mb) -> float4 {
             const int c = (2 * u) ^ x;                          // == (2u + h) ^ (r & 15)
             return *reinterpret_cast<const float4*>(tile + ((r + 32 * mb) * CH + c) * 16);
         };
         float4 a0 = lda(0, 0), a1 = lda(0, 1);
+        const f32x16 zero = {0};
+        acc0 = zero; acc1 = zero;
 #pragma unroll
         for (int u = 0; u < D / 8; ++u) {
             float4 n0 = a0, n1 = a1;
@@ -155,48 +165,72 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, qreg[4 * u + 3], acc1, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             a0 = n0; a1 = n1;
+            // issue the next tile's LDS-DMA under the MFMAs already queued (not at the tile
+            // top, where its address arithmetic would sit between the barrier and MFMA #1)
+            if (u == 1 && next_tile >= 0) { stage(buf ^ 1, next_tile); __builtin_amdgcn_sched_barrier(0); }
         }
+    };
 
-        // ---- fused top-k epilogue.  acc[j] is (corpus row base + (j&3) + 8*(j>>2) + 4h, query r)
-        const long tile_row0 = row_lo + (long)t * TILE_ROWS;
-        const bool ragged = tile_row0 + TILE_ROWS > row_hi;     // wave-uniform, last tile only
+    if (ntiles > 0) stage(0, tile_lo);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ntiles + 1 iterations: the last one only drains the late waves' deferred epilogue.
+    for (int t = 0; t <= ntiles; ++t) {
+        const int buf = t & 1;
+        const int next_tile = t + 1 < ntiles ? tile_lo + t + 1 : -1;
+        if (!late && t < ntiles) mfma_tile(buf, next_tile);
+
+        // ---- fused top-k epilogue of tile te (this tile for waves 0-3, the previous one for 4-7).
+        // acc[j] is (corpus row base + (j&3) + 8*(j>>2) + 4h, query r).
+        const int te = late ? t - 1 : t;
+        if (te >= 0 && te < ntiles) {
+            const long tile_row0 = (long)(tile_lo + te) * tile_step_rows;
+            const bool ragged = tile_row0 + TILE_ROWS > n;       // wave-uniform, last tile only
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            f32x16 a = mb ? acc1 : acc0;
-            const int base = (int)tile_row0 + mb * 32 + 4 * h;
-            if (ragged) {
+            for (int mb = 0; mb < 2; ++mb) {
+                f32x16 a = mb ? acc1 : acc0;
+                const int base = (int)tile_row0 + mb * 32 + 4 * h;
+                if (ragged) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (base + (j & 3) + 8 * (j >> 2) >= (int)row_hi) a[j] = -INFINITY;
-            }
-            float m = fmaxf(fmaxf(a[0], a[1]), a[2]);
+                    for (int j = 0; j < 16; ++j)
+                        if (base + (j & 3) + 8 * (j >> 2) >= n) a[j] = -INFINITY;
+                }
+                float m = fmaxf(fmaxf(a[0], a[1]), a[2]);
 #pragma unroll
-            for (int j = 3; j < 15; j += 2) m = fmaxf(fmaxf(m, a[j]), a[j + 1]);
-            m = fmaxf(m, a[15]);
-            if (__builtin_amdgcn_ballot_w64(m > ls[KP - 1]) != 0) {
-                // A passing score parks in the lane's one pending slot; the 80-instruction
-                // sorted insert runs only when some lane needs its slot again (then every
-                // lane's pending entry goes in with that same pass).  ls[KP-1] may therefore
-                // lag behind -- it only admits extra candidates, never drops one.
+                for (int j = 3; j < 15; j += 2) m = fmaxf(fmaxf(m, a[j]), a[j + 1]);
+                m = fmaxf(m, a[15]);
+                if (PRE) { pend_s = fmaxf(pend_s, m); continue; }
+                if (__builtin_amdgcn_ballot_w64(m > ls[KP - 1]) != 0) {
+                    // A passing score parks in the lane's one pending slot; the 80-instruction
+                    // sorted insert runs only when some lane needs its slot again (then every
+                    // lane's pending entry goes in with that same pass).  ls[KP-1] may therefore
+                    // lag behind -- it only admits extra candidates, never drops one.
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const bool pass = a[j] > ls[KP - 1];
-                    if (__builtin_amdgcn_ballot_w64(pass) != 0) {
-                        if (__builtin_amdgcn_ballot_w64(pass && pend_i >= 0) != 0) {
-                            list_insert<KP>(ls, li, pend_s, pend_i);
-                            pend_s = -INFINITY; pend_i = -1;
+                    for (int j = 0; j < 16; ++j) {
+                        const bool pass = a[j] > ls[KP - 1];
+                        if (__builtin_amdgcn_ballot_w64(pass) != 0) {
+                            if (__builtin_amdgcn_ballot_w64(pass && pend_i >= 0) != 0) {
+                                list_insert<KP>(ls, li, pend_s, pend_i);
+                                pend_s = -INFINITY; pend_i = -1;
+                            }
+                            const bool still = a[j] > ls[KP - 1];
+                            pend_s = still ? a[j] : pend_s;
+                            pend_i = still ? base + (j & 3) + 8 * (j >> 2) : pend_i;
                         }
-                        const bool still = a[j] > ls[KP - 1];
-                        pend_s = still ? a[j] : pend_s;
-                        pend_i = still ? base + (j & 3) + 8 * (j >> 2) : pend_i;
                     }
                 }
             }
         }
+        if (late && t < ntiles) mfma_tile(buf, next_tile);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile landed
         __syncthreads();                                   // ... everyone's did, and this buffer is free
     }
 
+    if (PRE) {      // lane maximum -> cand_s[q][split*2 + h]
+        if (q_glob < nq) cand_s[(size_t)q_glob * (2 * S) + (size_t)split * 2 + h] = pend_s;
+        return;
+    }
     list_insert<KP>(ls, li, pend_s, pend_i);   // no-op for lanes with an empty slot (-inf)
     // ---- spill the lane lists: cand[q][split*2 + h][KP]
     if (q_glob < nq) {
@@ -219,55 +253,28 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
 //                  through the exhaustive path.
 constexpr int SEL_THREADS = 256;
 constexpr int SEL_MAX_K2 = 128;
+constexpr unsigned long long EMPTY_KEY = 0x007FFFFF00000000ull;   // make_key(-inf, -1)
 
-__global__ __launch_bounds__(SEL_THREADS) void k_select_rescore(
-    const float* __restrict__ Q, const float* __restrict__ C, int d, int L,
-    const float* __restrict__ cand_s, const int* __restrict__ cand_i, int k, int K2,
-    long id_offset, float corpus_max_norm, float* __restrict__ D_out, long* __restrict__ I_out,
-    int* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int M = L * KP;
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);          // [M]
-    unsigned long long* sel = keys + M;                                              // [SEL_MAX_K2]
-    double* resc = reinterpret_cast<double*>(sel + SEL_MAX_K2);                      // [SEL_MAX_K2]
-    float* qrow = reinterpret_cast<float*>(resc + SEL_MAX_K2);                       // [d]
-    __shared__ unsigned long long wmax[SEL_THREADS / 64];
-    __shared__ unsigned long long s_maxlast;
-    __shared__ float s_qnorm2;
-
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const float* cs = cand_s + (size_t)q * M;
-    const int* ci = cand_i + (size_t)q * M;
+// Load the L*KP candidates of query q as keys into LDS; returns (via wave 0 lane 0 in *maxlast)
+// the largest tail key over FULL lists.  All threads of the block must call.
+__device__ __forceinline__ unsigned long long load_keys(const float* cs, const int* ci, int M,
+                                                        unsigned long long* keys, int tid) {
     unsigned long long lastmax = 0;
     for (int i = tid; i < M; i += SEL_THREADS) {
-        const unsigned long long key = make_key(cs[i], ci[i]);
+        const int id = ci[i];
+        const unsigned long long key = id >= 0 ? make_key(cs[i], id) : EMPTY_KEY;
         keys[i] = key;
-        if ((i % KP) == KP - 1 && ci[i] >= 0 && key > lastmax) lastmax = key;  // tail of a FULL list
+        if ((i % KP) == KP - 1 && id >= 0 && key > lastmax) lastmax = key;   // tail of a FULL list
     }
-    float qs = 0.f;
-    for (int i = tid; i < d; i += SEL_THREADS) {
-        const float v = Q[(size_t)q * d + i];
-        qrow[i] = v;
-        qs += v * v;
-    }
-    // block reductions (max of list tails, |q|^2)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(lastmax, o);
-        lastmax = other > lastmax ? other : lastmax;
-        qs += __shfl_xor(qs, o);
-    }
-    __shared__ float wq[SEL_THREADS / 64];
-    if (lane == 0) { wmax[wv] = lastmax; wq[wv] = qs; }
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long mm = 0; float qq = 0.f;
-        for (int w = 0; w < SEL_THREADS / 64; ++w) { mm = wmax[w] > mm ? wmax[w] : mm; qq += wq[w]; }
-        s_maxlast = mm; s_qnorm2 = qq;
-    }
-    __syncthreads();
+    return lastmax;
+}
 
-    // ---- K2 rounds of block-wide arg-max extraction (keys are unique per real candidate)
+// K2 rounds of block-wide arg-max extraction (keys of real candidates are unique).  sel[it]
+// receives the it-th best key (0 once the candidates are exhausted).
+__device__ __forceinline__ void extract_top(unsigned long long* keys, int M, int K2,
+                                            unsigned long long* sel, unsigned long long* wmax,
+                                            int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
     for (int it = 0; it < K2; ++it) {
         unsigned long long best = 0; int bidx = -1;
         for (int i = tid; i < M; i += SEL_THREADS) {
@@ -289,44 +296,125 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_rescore(
         if (tid == 0) sel[it] = gbest;
         __syncthreads();
     }
+}
 
-    // ---- float64 re-score of the selected rows, one thread per candidate, sequential in k
+// Sampled pre-pass -> admission threshold of the main pass: tau[q] = the float just below the
+// K2-th largest of the L lane maxima of query q.  Each maximum is the score of a distinct corpus
+// row, so at least K2 rows score above tau[q] and no row at or below it can be among the best
+// K2.  One wave per query; L <= 512.
+__global__ __launch_bounds__(64) void k_tau(const float* __restrict__ pre_max, int L, int K2,
+                                            float* __restrict__ tau) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    unsigned v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i;
+        v[i] = idx < L ? f2ord(pre_max[(size_t)q * L + idx]) : 0u;
+    }
+    unsigned cur = 0;
+    for (int it = 0; it < K2; ++it) {      // K2 rounds: wave-wide max, remove one instance
+        unsigned best = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) best = v[i] > best ? v[i] : best;
+        unsigned w = best;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned other = __shfl_xor(w, o); w = other > w ? other : w; }
+        cur = w;
+        const unsigned long long owners = __builtin_amdgcn_ballot_w64(best == w);
+        const int first = __builtin_ctzll(owners);
+        if (lane == first) {
+            bool done = false;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (!done && v[i] == w) { v[i] = 0u; done = true; }
+        }
+    }
+    if (lane == 0) tau[q] = (cur > f2ord(-INFINITY)) ? ord2f(cur - 1) : -INFINITY;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void k_select_rescore(
+    const float* __restrict__ Q, const float* __restrict__ C, int d, int L,
+    const float* __restrict__ cand_s, const int* __restrict__ cand_i, const float* __restrict__ tau0,
+    int k, int K2, long id_offset, float corpus_max_norm, float* __restrict__ D_out,
+    long* __restrict__ I_out, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = L * KP;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);          // [M]
+    unsigned long long* sel = keys + M;                                              // [SEL_MAX_K2]
+    double* resc = reinterpret_cast<double*>(sel + SEL_MAX_K2);                      // [SEL_MAX_K2]
+    float* qrow = reinterpret_cast<float*>(resc + SEL_MAX_K2);                       // [d]
+    float* rows = qrow + d;                                                          // [K2][d + 4]
+    __shared__ unsigned long long wmax[SEL_THREADS / 64];
+    __shared__ float wq[SEL_THREADS / 64];
+    __shared__ unsigned long long s_maxlast;
+    __shared__ float s_qnorm2;
+    __shared__ double s_kth;
+    __shared__ int s_nvalid;
+
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned long long lastmax = load_keys(cand_s + (size_t)q * M, cand_i + (size_t)q * M, M, keys, tid);
+    float qs = 0.f;
+    for (int i = tid; i < d; i += SEL_THREADS) {
+        const float v = Q[(size_t)q * d + i];
+        qrow[i] = v;
+        qs += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(lastmax, o);
+        lastmax = other > lastmax ? other : lastmax;
+        qs += __shfl_xor(qs, o);
+    }
+    if (lane == 0) { wmax[wv] = lastmax; wq[wv] = qs; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long mm = 0; float qq = 0.f;
+        for (int w = 0; w < SEL_THREADS / 64; ++w) { mm = wmax[w] > mm ? wmax[w] : mm; qq += wq[w]; }
+        s_maxlast = mm; s_qnorm2 = qq; s_nvalid = 0; s_kth = 0.0;
+    }
+    __syncthreads();
+
+    extract_top(keys, M, K2, sel, wmax, tid);
+
+    // ---- stage the K2 selected corpus rows in LDS (coalesced 16-byte loads, all threads)
+    const int ldr = d + 4;
+    const int nv = d / 4;
+    for (int i = tid; i < K2 * nv; i += SEL_THREADS) {
+        const int c = i / nv, v = i % nv;
+        const unsigned long long key = sel[c];
+        const int id = key_id(key);
+        if (key != 0 && id >= 0)
+            *reinterpret_cast<float4*>(rows + c * ldr + v * 4) =
+                *reinterpret_cast<const float4*>(C + (size_t)id * d + v * 4);
+    }
+    __syncthreads();
+    // ---- float64 re-score, one thread per candidate, sequential in k (the canonical order)
     if (tid < K2) {
         const int id = key_id(sel[tid]);
         double acc = 0.0;
         if (id >= 0 && sel[tid] != 0) {
-            const float4* row = reinterpret_cast<const float4*>(C + (size_t)id * d);
-            for (int kk = 0; kk < d / 4; ++kk) {
-                const float4 v = row[kk];
-                acc += (double)qrow[4 * kk + 0] * (double)v.x;
-                acc += (double)qrow[4 * kk + 1] * (double)v.y;
-                acc += (double)qrow[4 * kk + 2] * (double)v.z;
-                acc += (double)qrow[4 * kk + 3] * (double)v.w;
-            }
+            const float* row = rows + tid * ldr;
+            for (int kk = 0; kk < d; ++kk) acc += (double)qrow[kk] * (double)row[kk];
         }
         resc[tid] = acc;
     }
     __syncthreads();
     // ---- rank by (float32(score64) desc, id asc); write the first k
-    __shared__ double s_kth;
-    __shared__ int s_nvalid;
-    if (tid == 0) { s_nvalid = 0; s_kth = 0.0; }
-    __syncthreads();
     if (tid < K2) {
         const int id = key_id(sel[tid]);
         const bool valid = sel[tid] != 0 && id >= 0;
         if (valid) {
-            const float s = (float)resc[tid];
+            const float sc = (float)resc[tid];
             int rank = 0;
             for (int j = 0; j < K2; ++j) {
                 const int idj = key_id(sel[j]);
                 if (j == tid || sel[j] == 0 || idj < 0) continue;
                 const float sj = (float)resc[j];
-                if (sj > s || (sj == s && idj < id)) ++rank;
+                if (sj > sc || (sj == sc && idj < id)) ++rank;
             }
             atomicAdd(&s_nvalid, 1);
             if (rank < k) {
-                D_out[(size_t)q * k + rank] = s;
+                D_out[(size_t)q * k + rank] = sc;
                 I_out[(size_t)q * k + rank] = (long)id + id_offset;
             }
             if (rank == k - 1) s_kth = resc[tid];
@@ -338,14 +426,17 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_rescore(
         I_out[(size_t)q * k + j] = -1;
     }
     if (tid == 0) {
-        // Everything NOT selected has float32 key below sel[K2-1] (or below the tail of a full
-        // list).  Proven exact when (a) no full list's tail outranks the selection edge and
-        // (b) edge score + 2*B < k-th re-scored score, B = d * 2^-24 * |q| * max|c| bounding the
+        // A row that was NOT selected (a) lost to a full list's tail, (b) scored at or below the
+        // pre-pass threshold tau0, or (c) is a candidate ranked below sel[K2-1].  Proven exact
+        // when no full list's tail and no tau0 outranks the selection edge, and
+        // edge score + 2*B < k-th re-scored score, with B = d * 2^-24 * |q| * max|c| bounding the
         // float32 fma-chain error of any row.
         int st = 0;
         const unsigned long long edge = sel[K2 - 1];
+        const bool edge_real = edge != 0 && key_id(edge) >= 0;
         if (s_maxlast > edge) st = 1;
-        if (edge != 0 && key_id(edge) >= 0 && s_nvalid >= k) {
+        if (tau0 != nullptr && tau0[q] > -INFINITY && !(edge_real && key_score(edge) > tau0[q])) st = 1;
+        if (edge_real && s_nvalid >= k) {
             const double B = (double)d * 5.9604644775390625e-08 * sqrt((double)s_qnorm2) *
                              (double)corpus_max_norm * 1.02;
             if ((double)key_score(edge) + 2.0 * B >= s_kth) st = 1;
@@ -388,24 +479,70 @@ static int pick_splits(long n, int G) {
     return S;
 }
 
+struct ScanPlan {
+    int G, S, L, K2;
+    int total_tiles, tiles_per_split;       // main pass
+    int pre_tiles, pre_tiles_per_split, pre_step_rows;   // sampled pre-pass (pre_tiles == 0: none)
+};
+
+static ScanPlan make_plan(long nq, long n, int k) {
+    ScanPlan p;
+    p.G = (int)((nq + WG_QUERIES - 1) / WG_QUERIES);
+    p.S = pick_splits(n, p.G);
+    p.L = 2 * p.S;
+    p.K2 = k + (k <= 12 ? KP - k : 12);
+    if (p.L * KP < p.K2) p.K2 = p.L * KP;
+    p.total_tiles = (int)((n + TILE_ROWS - 1) / TILE_ROWS);
+    p.tiles_per_split = (p.total_tiles + p.S - 1) / p.S;
+    // Pre-pass sample: about 2n/L rows (so a lane list of the main pass admits ~KP rows),
+    // at least 4 tiles a split, evenly spaced tiles; skipped unless it is < 1/8 of the corpus.
+    long want_rows = 2 * n / p.L;
+    if (want_rows < 4L * TILE_ROWS * p.S) want_rows = 4L * TILE_ROWS * p.S;
+    int ptps = (int)((want_rows / TILE_ROWS + p.S - 1) / p.S);
+    p.pre_tiles = 0; p.pre_tiles_per_split = 0; p.pre_step_rows = 0;
+    if ((long)ptps * p.S * 8 <= p.total_tiles && p.L >= p.K2 && p.L <= 512) {
+        p.pre_tiles_per_split = ptps;
+        p.pre_tiles = ptps * p.S;
+        p.pre_step_rows = (p.total_tiles / p.pre_tiles) * TILE_ROWS;
+    }
+    return p;
+}
+
 size_t ip_topk_workspace_bytes(long nq, long n, int d, int k) {
-    const int G = (int)((nq + WG_QUERIES - 1) / WG_QUERIES);
-    const int S = pick_splits(n, G);
-    return (size_t)nq * 2 * S * KP * 8 + 256;
+    const ScanPlan p = make_plan(nq, n, k);
+    return (size_t)nq * p.L * KP * 8 + (size_t)nq * 4 + 256;
 }
 
 template <int D>
-static int launch_scan(const float* q, int nq, const float* c, int n, int S, int G, int rps,
-                       float* cs, int* ci, hipStream_t st) {
+static void set_lds_attr() {
+    const int lds = 2 * TILE_ROWS * D * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_topk_f32<D, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_topk_f32<D, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
+template <int D>
+static int launch_scan(const float* q, int nq, const float* c, int n, const ScanPlan& p, bool pre,
+                       const float* tau, float* cs, int* ci, hipStream_t st) {
     const size_t lds = 2 * TILE_ROWS * D * 4;
     static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_topk_f32<D>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(k_ip_topk_f32<D>, dim3(S * G), dim3(512), lds, st, q, nq, c, n, rps, S, G, cs, ci);
+    if (!attr_done) { set_lds_attr<D>(); attr_done = true; }
+    if (pre)
+        hipLaunchKernelGGL((k_ip_topk_f32<D, true>), dim3(p.S * p.G), dim3(512), lds, st, q, nq, c, n,
+                           p.pre_tiles_per_split, p.pre_tiles, p.pre_step_rows, p.S, p.G,
+                           (const float*)nullptr, cs, ci);
+    else
+        hipLaunchKernelGGL((k_ip_topk_f32<D, false>), dim3(p.S * p.G), dim3(512), lds, st, q, nq, c, n,
+                           p.tiles_per_split, p.total_tiles, TILE_ROWS, p.S, p.G, tau, cs, ci);
     return check_launch("k_ip_topk_f32");
+}
+
+static int scan_dispatch(int d, const float* q, int nq, const float* c, int n, const ScanPlan& p,
+                         bool pre, const float* tau, float* cs, int* ci, hipStream_t st) {
+    if (d == 64) return launch_scan<64>(q, nq, c, n, p, pre, tau, cs, ci, st);
+    if (d == 128) return launch_scan<128>(q, nq, c, n, p, pre, tau, cs, ci, st);
+    return launch_scan<256>(q, nq, c, n, p, pre, tau, cs, ci, st);
 }
 
 int ip_topk_f32(const float* q, long nq, const float* c, long n, int d, int k, long id_offset,
@@ -413,27 +550,35 @@ int ip_topk_f32(const float* q, long nq, const float* c, long n, int d, int k, l
                 size_t ws_bytes, hipStream_t st) {
     if (nq <= 0 || n <= 0 || k <= 0) { set_error("ip_topk: nq, n, k must be positive"); return SSS_EINVAL; }
     if (d != 64 && d != 128 && d != 256) { set_error("ip_topk: d must be 64, 128 or 256 (got %d)", d); return SSS_EINVAL; }
-    if (n >= (1L << 31) || nq >= (1L << 31)) { set_error("ip_topk: n and nq must be < 2^31 per shard"); return SSS_EINVAL; }
-    int K2 = k + (k <= 12 ? KP - k : 12);
-    if (K2 > SEL_MAX_K2) { set_error("ip_topk: k too large (max %d)", SEL_MAX_K2 - 12); return SSS_EINVAL; }
-    const int G = (int)((nq + WG_QUERIES - 1) / WG_QUERIES);
-    const int S = pick_splits(n, G);
-    if (2 * S * KP < K2) K2 = 2 * S * KP;
+    if (n >= (1L << 31) - 2 * TILE_ROWS || nq >= (1L << 31)) { set_error("ip_topk: n and nq must be < 2^31 per shard"); return SSS_EINVAL; }
+    if (k + 12 > SEL_MAX_K2) { set_error("ip_topk: k too large (max %d)", SEL_MAX_K2 - 12); return SSS_EINVAL; }
+    const ScanPlan p = make_plan(nq, n, k);
     const size_t need = ip_topk_workspace_bytes(nq, n, d, k);
     if (ws_bytes < need) { set_error("ip_topk: workspace %zu < %zu", ws_bytes, need); return SSS_EWORKSPACE; }
-    long rps = (n + S - 1) / S;
-    rps = (rps + TILE_ROWS - 1) / TILE_ROWS * TILE_ROWS;
     float* cs = reinterpret_cast<float*>(ws);
-    int* ci = reinterpret_cast<int*>(cs + (size_t)nq * 2 * S * KP);
+    int* ci = reinterpret_cast<int*>(cs + (size_t)nq * p.L * KP);
+    float* tau = reinterpret_cast<float*>(ci + (size_t)nq * p.L * KP);
     int rc;
-    if (d == 64) rc = launch_scan<64>(q, (int)nq, c, (int)n, S, G, (int)rps, cs, ci, st);
-    else if (d == 128) rc = launch_scan<128>(q, (int)nq, c, (int)n, S, G, (int)rps, cs, ci, st);
-    else rc = launch_scan<256>(q, (int)nq, c, (int)n, S, G, (int)rps, cs, ci, st);
+    const size_t key_lds = (size_t)p.L * KP * 8;
+    if (p.pre_tiles > 0) {
+        rc = scan_dispatch(d, q, (int)nq, c, (int)n, p, true, nullptr, cs, ci, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_tau, dim3((unsigned)nq), dim3(64), 0, st, cs, p.L, p.K2, tau);
+        rc = check_launch("k_tau");
+        if (rc) return rc;
+    }
+    const float* tau_in = p.pre_tiles > 0 ? tau : nullptr;
+    rc = scan_dispatch(d, q, (int)nq, c, (int)n, p, false, tau_in, cs, ci, st);
     if (rc) return rc;
-    const int L = 2 * S;
-    const size_t lds = (size_t)L * KP * 8 + SEL_MAX_K2 * 16 + (size_t)d * 4;
-    hipLaunchKernelGGL(k_select_rescore, dim3((unsigned)nq), dim3(SEL_THREADS), lds, st, q, c, d, L, cs, ci,
-                       k, K2, id_offset, corpus_max_norm, D_out, I_out, status);
+    const size_t lds = key_lds + SEL_MAX_K2 * 16 + (size_t)d * 4 + (size_t)p.K2 * (d + 4) * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_rescore),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_select_rescore, dim3((unsigned)nq), dim3(SEL_THREADS), lds, st, q, c, d, p.L, cs, ci,
+                       tau_in, k, p.K2, id_offset, corpus_max_norm, D_out, I_out, status);
     return check_launch("k_select_rescore");
 }
 
