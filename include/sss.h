@@ -72,6 +72,50 @@ int sss_topk_merge(const float* D_in, const int64_t* I_in, int shards, int64_t n
 int sss_gather_rows(const float* table, const int64_t* ids, int64_t n, int d, float* out,
                     int64_t ld_out, void* stream);
 
+/* Dense node transform  y[n, m] = x[n, k] * w[m, k]^T (+ bias[m])  on the f32 MFMA.  Replaces
+ * the nn.Linear / lazy Linear / GRUCell matmuls inside PyG GATConv (lin_src), GatedGraphConv
+ * (x @ weight; pass weight transposed) and PositionalAttentionPooling (reference
+ * model/gnn.py:54,58,186-190).  k % 32 == 0; ldx, ldw multiples of 4 floats. */
+int sss_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
+               int64_t ldy, int64_t n, int m, int k, void* stream);
+
+/* GATConv.propagate for one edge type (instantiated model/gnn.py:54):
+ * CSR by target (rowptr [n_dst+1], col = source ids, int32; the PyG self-loop rewrite is already
+ * applied by the caller): e = leaky_relu(a_src[j] + a_dst[i], 0.2), per-target softmax with the
+ * +1e-16 of PyG, out[i] = sum_j w_ij xs[j] + bias (relu != 0: then max(.,0)).
+ * a_src / a_dst are strided scalars (element i at a[i * ld]). */
+int sss_gat_aggregate(const float* xs, int64_t ld_xs, const float* a_src, int64_t ld_as,
+                      const float* a_dst, int64_t ld_ad, const int32_t* rowptr, const int32_t* col,
+                      int64_t n_dst, int h, const float* bias, int relu, float* out, int64_t ld_out,
+                      void* stream);
+
+/* GatedGraphConv.propagate, aggr='add' (Appendix A.3; model/gnn.py:58):
+ * out[i] = sum_{e in row i} (w[e] if w else 1) * m[col[e]]. */
+int sss_csr_weighted_sum(const float* m, int64_t ld_m, const int32_t* rowptr, const int32_t* col,
+                         const float* w, int64_t n_dst, int h, float* out, int64_t ld_out, void* stream);
+
+/* torch.nn.GRUCell gate math (inside GatedGraphConv) + HeteroConv(aggr='sum') + relu
+ * (model/gnn.py:59,72): gi = W_ih m + b_ih [n,3h], gh = W_hh x + b_hh [n,3h], x zero-padded from
+ * d_x to h columns; out = relu(add + (1-z) n + z x).  add may be NULL. */
+int sss_gru_combine(const float* gi, int64_t ld_gi, const float* gh, int64_t ld_gh, const float* x,
+                    int64_t ld_x, int d_x, const float* add, int64_t ld_add, int64_t n, int h, float* out,
+                    int64_t ld_out, void* stream);
+
+/* PositionalAttentionPooling.forward pieces (model/gnn.py:193-217).
+ * expand: node[e, :d_lin] = tanh(lin[src_row[e]]), node[e, d_lin:] = tanh(pos_emb[pos_id[e]]);
+ *         rows e < n_clicks read lin_p (product clicks, repeat_interleave by cnt), the rest lin_q.
+ * segment_pool: per graph g over expanded rows [pptr[g],pptr[g+1]) and n_clicks+[qptr[g],qptr[g+1]):
+ *         watt == NULL: mean (global_mean_pool); else mean(node * att), att = watt . sigmoid(a + bcoarse[g]).
+ * segment_ptr: ptr[g] = lower_bound(batch, g) for g in [0, n_graphs] (batch sorted, int64). */
+int sss_pool_expand(const float* lin_p, const float* lin_q, int64_t ld_lin, const int32_t* src_row,
+                    const int32_t* pos_id, int64_t n_clicks, int64_t n_exp, int d_lin, int p,
+                    const float* pos_emb, float* node, int64_t ld_node, void* stream);
+int sss_segment_pool(const float* node, int64_t ld_node, const int32_t* pptr, const int32_t* qptr,
+                     int64_t n_clicks, int64_t n_graphs, int d, const float* a, int64_t ld_a,
+                     const float* bcoarse, int64_t ld_b, const float* watt, float* out, int64_t ld_out,
+                     void* stream);
+int sss_segment_ptr(const int64_t* batch, int64_t n, int64_t n_graphs, int32_t* ptr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,19 @@ _SIGNATURES = {
                                        c_void_p]),
     "sss_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "sss_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "sss_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                           c_int, c_int, c_void_p]),
+    "sss_gat_aggregate": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                  c_int64, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "sss_csr_weighted_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                     c_void_p, c_int64, c_void_p]),
+    "sss_gru_combine": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p,
+                                c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "sss_pool_expand": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sss_segment_pool": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
+                                 c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sss_segment_ptr": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
 }
 
 

@@ -36,6 +36,17 @@ int ip_topk_exhaustive(const float*, const int*, long, const float*, long, int, 
 int normalize_rows(float*, long, int, long, float, int, hipStream_t);
 int row_norm_max(const float*, long, int, float*, hipStream_t);
 int gather_rows(const float*, const long*, long, int, float*, long, hipStream_t);
+int linear_f32(const float*, long, const float*, long, const float*, float*, long, long, int, int, hipStream_t);
+int gat_aggregate(const float*, long, const float*, long, const float*, long, const int*, const int*, long, int,
+                  const float*, int, float*, long, hipStream_t);
+int csr_weighted_sum(const float*, long, const int*, const int*, const float*, long, int, float*, long, hipStream_t);
+int gru_combine(const float*, long, const float*, long, const float*, long, int, const float*, long, long, int,
+                float*, long, hipStream_t);
+int pool_expand(const float*, const float*, long, const int*, const int*, long, long, int, int, const float*, float*,
+                long, hipStream_t);
+int segment_pool(const float*, long, const int*, const int*, long, long, int, const float*, long, const float*, long,
+                 const float*, float*, long, hipStream_t);
+int segment_ptr(const long*, long, long, int*, hipStream_t);
 
 }  // namespace sss
 
@@ -78,6 +89,41 @@ int sss_topk_merge(const float* D_in, const int64_t* I_in, int shards, int64_t n
 int sss_gather_rows(const float* table, const int64_t* ids, int64_t n, int d, float* out, int64_t ld_out,
                     void* stream) {
     return sss::gather_rows(table, reinterpret_cast<const long*>(ids), n, d, out, ld_out, ST(stream));
+}
+
+int sss_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
+               int64_t n, int m, int k, void* stream) {
+    return sss::linear_f32(x, ldx, w, ldw, bias, y, ldy, n, m, k, ST(stream));
+}
+int sss_gat_aggregate(const float* xs, int64_t ld_xs, const float* a_src, int64_t ld_as, const float* a_dst,
+                      int64_t ld_ad, const int32_t* rowptr, const int32_t* col, int64_t n_dst, int h,
+                      const float* bias, int relu, float* out, int64_t ld_out, void* stream) {
+    return sss::gat_aggregate(xs, ld_xs, a_src, ld_as, a_dst, ld_ad, rowptr, col, n_dst, h, bias, relu, out, ld_out,
+                              ST(stream));
+}
+int sss_csr_weighted_sum(const float* m, int64_t ld_m, const int32_t* rowptr, const int32_t* col, const float* w,
+                         int64_t n_dst, int h, float* out, int64_t ld_out, void* stream) {
+    return sss::csr_weighted_sum(m, ld_m, rowptr, col, w, n_dst, h, out, ld_out, ST(stream));
+}
+int sss_gru_combine(const float* gi, int64_t ld_gi, const float* gh, int64_t ld_gh, const float* x, int64_t ld_x,
+                    int d_x, const float* add, int64_t ld_add, int64_t n, int h, float* out, int64_t ld_out,
+                    void* stream) {
+    return sss::gru_combine(gi, ld_gi, gh, ld_gh, x, ld_x, d_x, add, ld_add, n, h, out, ld_out, ST(stream));
+}
+int sss_pool_expand(const float* lin_p, const float* lin_q, int64_t ld_lin, const int32_t* src_row,
+                    const int32_t* pos_id, int64_t n_clicks, int64_t n_exp, int d_lin, int p, const float* pos_emb,
+                    float* node, int64_t ld_node, void* stream) {
+    return sss::pool_expand(lin_p, lin_q, ld_lin, src_row, pos_id, n_clicks, n_exp, d_lin, p, pos_emb, node, ld_node,
+                            ST(stream));
+}
+int sss_segment_pool(const float* node, int64_t ld_node, const int32_t* pptr, const int32_t* qptr, int64_t n_clicks,
+                     int64_t n_graphs, int d, const float* a, int64_t ld_a, const float* bcoarse, int64_t ld_b,
+                     const float* watt, float* out, int64_t ld_out, void* stream) {
+    return sss::segment_pool(node, ld_node, pptr, qptr, n_clicks, n_graphs, d, a, ld_a, bcoarse, ld_b, watt, out,
+                             ld_out, ST(stream));
+}
+int sss_segment_ptr(const int64_t* batch, int64_t n, int64_t n_graphs, int32_t* ptr, void* stream) {
+    return sss::segment_ptr(reinterpret_cast<const long*>(batch), n, n_graphs, ptr, ST(stream));
 }
 
 }  // extern "C"

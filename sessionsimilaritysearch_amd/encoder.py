@@ -1,0 +1,350 @@
+"""Session encoder: drop-in for the reference's ``UnifyPoolingGraphLevelEncoder.forward``
+(``model/model.py:279-351``): node features -> ``HeteroGGNN`` (``model/gnn.py:43-81``) ->
+``PositionalAttentionPooling`` (``model/gnn.py:183-217``) -> one vector per session.
+
+Every arithmetic step runs in the HIP kernels of ``libsss.so`` through the C ABI
+(``include/sss.h``); torch owns device memory, the stream and the integer index preparation
+(CSR by target, repeat_interleave).  There is no CPU fallback.
+
+Out of scope, by design: the reference's BERT/ELECTRA text encoder
+(``model/NodeEmbedding.py:100-125``).  Node input features are rows of two tables --
+``item_table`` (``NodeAsinEmbedding``, ``model/NodeEmbedding.py:128-138``) and ``query_table``
+(stand-in for the text features of query nodes) -- or precomputed float features passed as
+``data[node_type].feat``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .sessions import ASIN_NUM, EDGE_PP, EDGE_PQ, EDGE_QP, MAX_SEQ_LEN, QUERY_VOCAB
+
+ALPHA_PAD = 32          # extra output columns of the fused node transforms (2 used: alpha_src, alpha_dst)
+
+
+@dataclass
+class EncoderConfig:
+    d_in: int = 128                 # node input feature width
+    h: int = 128                    # GNN width (reference CFG.gnn_nout = 800, config.py:16)
+    n_layers: int = 2               # reference CFG.gnn_nlayers = 3, config.py:21
+    d_out: int = 128                # session vector width D (reference gnn_nout * 2 = 1600)
+    max_seq_len: int = MAX_SEQ_LEN  # positional table is [P, P] (model/gnn.py:188)
+    n_items: int = ASIN_NUM
+    n_query: int = QUERY_VOCAB
+    # "pyg_bipartite_global": PyG GATConv(add_self_loops=True) edge rewrite in batch-global
+    # indices (SURVEY.md hard part H3) -- the parity default.  "none": independent graphs.
+    self_loop_rule: str = "pyg_bipartite_global"
+
+    @property
+    def node_width(self) -> int:
+        return self.d_in + self.n_layers * self.h
+
+    def validate(self):
+        if self.d_in % 32 or self.h % 32 or self.d_out % 32:
+            raise ValueError("d_in, h and d_out must be multiples of 32")
+        if self.d_in > self.h:
+            raise ValueError("GatedGraphConv needs d_in <= h (the reference hits the same ValueError)")
+        if self.d_out <= self.max_seq_len:
+            raise ValueError("d_out must exceed max_seq_len")
+        if self.self_loop_rule not in ("pyg_bipartite_global", "none"):
+            raise ValueError("unknown self_loop_rule")
+
+
+def _uniform(gen, shape, bound):
+    return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+
+
+def init_weights(cfg: EncoderConfig, seed: int, random_bias: bool = True, tables: bool = True):
+    """Random-init weights of the reference architecture: embeddings
+    N(0,1); nn.Linear default U(+-1/sqrt(fan_in)); GAT lin/att Glorot; GGC weight and GRUCell
+    U(+-1/sqrt(h)).  ``random_bias`` draws the GAT biases too (PyG's default is zeros)."""
+    cfg.validate()
+    g = torch.Generator().manual_seed(seed)
+    h, D, P, W = cfg.h, cfg.d_out, cfg.max_seq_len, cfg.node_width
+    w = {}
+    if tables:
+        w["item_table"] = torch.randn((cfg.n_items, cfg.d_in), generator=g)
+        w["query_table"] = torch.randn((cfg.n_query, cfg.d_in), generator=g)
+    for l in range(cfg.n_layers):
+        din = cfg.d_in if l == 0 else h
+        for name in ("gat_qp", "gat_pq"):
+            gl = math.sqrt(6.0 / (din + h))
+            w[f"{name}.{l}.lin_src"] = _uniform(g, (h, din), gl)
+            w[f"{name}.{l}.lin_dst"] = _uniform(g, (h, din), gl)
+            ga = math.sqrt(6.0 / (1 + h))
+            w[f"{name}.{l}.att_src"] = _uniform(g, (h,), ga)
+            w[f"{name}.{l}.att_dst"] = _uniform(g, (h,), ga)
+            w[f"{name}.{l}.bias"] = _uniform(g, (h,), 0.1) if random_bias else torch.zeros(h)
+        b = 1.0 / math.sqrt(h)
+        w[f"ggc.{l}.weight"] = _uniform(g, (h, h), b)
+        w[f"ggc.{l}.w_ih"] = _uniform(g, (3 * h, h), b)
+        w[f"ggc.{l}.w_hh"] = _uniform(g, (3 * h, h), b)
+        w[f"ggc.{l}.b_ih"] = _uniform(g, (3 * h,), b)
+        w[f"ggc.{l}.b_hh"] = _uniform(g, (3 * h,), b)
+    bw = 1.0 / math.sqrt(W)
+    for name in ("pool.query_lin", "pool.product_lin"):
+        w[name + ".w"] = _uniform(g, (D - P, W), bw)
+        w[name + ".b"] = _uniform(g, (D - P,), bw)
+    w["pool.pos_emb"] = torch.randn((P, P), generator=g)
+    bd = 1.0 / math.sqrt(D)
+    w["pool.node_lin.w"] = _uniform(g, (D, D), bd)
+    w["pool.node_lin.b"] = _uniform(g, (D,), bd)
+    w["pool.coarse_lin.w"] = _uniform(g, (D, D), bd)
+    w["pool.att_lin.w"] = _uniform(g, (D,), bd)
+    return {k: v.float().contiguous() for k, v in w.items()}
+
+
+def save_weights(path, weights):
+    """Flat weight file: named float32 arrays (``.npz``).  The reference pickles whole
+    ``nn.Module`` tuples (pretrain_filtered_amazon.py:605-610), which cannot be loaded without
+    torch_geometric; this is the build's replacement."""
+    np.savez(path, **{k: v.detach().cpu().numpy() for k, v in weights.items()})
+
+
+def load_weights(path):
+    with np.load(path, allow_pickle=False) as z:
+        return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def build_csr(edge_index: torch.Tensor, n_dst: int, n_src: int = 0, self_loops: bool = False,
+              edge_weight=None):
+    """COO [2, E] (row 0 = source j, row 1 = target i) -> CSR by target (rowptr int32 [n_dst+1],
+    col int32 [E']) keeping the original edge order inside every target's segment.  With
+    ``self_loops`` the PyG GATConv rewrite is applied first (Appendix A.2): drop edges whose
+    source index equals the target index, append (i -> i) for i < min(n_src, n_dst)."""
+    src, dst = edge_index[0], edge_index[1]
+    w = edge_weight
+    if self_loops:
+        keep = src != dst
+        loop = torch.arange(min(n_src, n_dst), dtype=src.dtype, device=src.device)
+        src = torch.cat([src[keep], loop])
+        dst = torch.cat([dst[keep], loop])
+        if w is not None:
+            w = torch.cat([w[keep], torch.ones(loop.numel(), dtype=w.dtype, device=w.device)])
+    order = torch.argsort(dst, stable=True)
+    col = src[order].to(torch.int32).contiguous()
+    counts = torch.bincount(dst, minlength=n_dst)
+    rowptr = torch.zeros(n_dst + 1, dtype=torch.int32, device=dst.device)
+    rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    wv = None if w is None else w[order].float().contiguous()
+    return rowptr, col, wv
+
+
+class SessionEncoder:
+    """``model.forward(data)`` drop-in (``UnifyPoolingGraphLevelEncoder``).  ``data`` is a
+    ``SessionBatch`` (or any object with the same attributes, e.g. a PyG hetero batch whose
+    node stores carry ``x`` ids) on the encoder's device."""
+
+    def __init__(self, cfg: EncoderConfig, weights: dict, device=None, use_edge_weight: bool = False,
+                 debug_nan_checks: bool = False):
+        cfg.validate()
+        if not torch.cuda.is_available():
+            raise _lib.SssError("no HIP device available: the encoder runs on MI355X only")
+        _lib.lib()
+        self.cfg = cfg
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.use_edge_weight = use_edge_weight      # the deployed path passes none (model/model.py:317)
+        self.debug_nan_checks = debug_nan_checks    # the reference's 3 host-syncing asserts
+        self.training = False
+        self._prepare(weights)
+
+    # -- nn.Module-flavoured conveniences the reference scripts call
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise _lib.SssError("SessionEncoder is bound to its construction device")
+        return self
+
+    def __call__(self, *a, **kw):
+        return self.forward(*a, **kw)
+
+    # ------------------------------------------------------------------ weight preparation
+    def _prepare(self, w):
+        cfg, dev = self.cfg, self.device
+        h = cfg.h
+        f64 = lambda t: t.detach().to(torch.float64)
+        d = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self.item_table = d(w["item_table"]) if "item_table" in w else None
+        self.query_table = d(w["query_table"]) if "query_table" in w else None
+        self.layers = []
+        for l in range(cfg.n_layers):
+            qp = {k: w[f"gat_qp.{l}.{k}"] for k in ("lin_src", "lin_dst", "att_src", "att_dst", "bias")}
+            pq = {k: w[f"gat_pq.{l}.{k}"] for k in ("lin_src", "lin_dst", "att_src", "att_dst", "bias")}
+            # alpha_src[j] = <lin_src x_j, att_src> = x_j . (lin_src^T att_src): one extra output row
+            v = lambda lin, att: (f64(lin).T @ f64(att)).float()
+            din = qp["lin_src"].shape[1]
+            # product-side fused transform: [xs_p (p->q messages) | m = x Wg | gh = W_hh x | a_s(pq) | a_d(qp)]
+            wp = torch.zeros((5 * h + ALPHA_PAD, din))
+            wp[0:h] = pq["lin_src"]
+            wp[h:2 * h, :] = w[f"ggc.{l}.weight"].T[:, :din]     # m = pad(x) @ weight
+            wp[2 * h:5 * h, :] = w[f"ggc.{l}.w_hh"][:, :din]
+            wp[5 * h] = v(pq["lin_src"], pq["att_src"])
+            wp[5 * h + 1] = v(qp["lin_dst"], qp["att_dst"])
+            bp = torch.zeros(5 * h + ALPHA_PAD)
+            bp[2 * h:5 * h] = w[f"ggc.{l}.b_hh"]
+            # query-side fused transform: [xs_q (q->p messages) | a_s(qp) | a_d(pq)]
+            wq = torch.zeros((h + ALPHA_PAD, din))
+            wq[0:h] = qp["lin_src"]
+            wq[h] = v(qp["lin_src"], qp["att_src"])
+            wq[h + 1] = v(pq["lin_dst"], pq["att_dst"])
+            self.layers.append(dict(
+                wp=d(wp), bp=d(bp), wq=d(wq), w_ih=d(w[f"ggc.{l}.w_ih"]), b_ih=d(w[f"ggc.{l}.b_ih"]),
+                bias_qp=d(qp["bias"]), bias_pq=d(pq["bias"]), din=din))
+        self.pool = dict(
+            wq=d(w["pool.query_lin.w"]), bq=d(w["pool.query_lin.b"]),
+            wp=d(w["pool.product_lin.w"]), bp=d(w["pool.product_lin.b"]),
+            pos=d(w["pool.pos_emb"]), wn=d(w["pool.node_lin.w"]), bn=d(w["pool.node_lin.b"]),
+            wc=d(w["pool.coarse_lin.w"]), watt=d(w["pool.att_lin.w"]))
+
+    # ------------------------------------------------------------------ C-ABI call helpers
+    def _st(self):
+        return _lib.stream_ptr(self.device)
+
+    def _linear(self, x, w, bias, n, m, k, out=None):
+        if out is None:
+            out = torch.empty((n, m), dtype=torch.float32, device=self.device)
+        rc = _lib.lib().sss_linear(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+                                   0 if bias is None else bias.data_ptr(), out.data_ptr(), out.stride(0),
+                                   n, m, k, self._st())
+        _lib.check(rc, "sss_linear")
+        return out
+
+    def _gat(self, xs, a_src, a_dst, csr, n_dst, bias, relu, out):
+        rowptr, col, _ = csr
+        rc = _lib.lib().sss_gat_aggregate(xs.data_ptr(), xs.stride(0), a_src.data_ptr(), a_src.stride(0),
+                                          a_dst.data_ptr(), a_dst.stride(0), rowptr.data_ptr(), col.data_ptr(),
+                                          n_dst, self.cfg.h, bias.data_ptr(), relu, out.data_ptr(), out.stride(0),
+                                          self._st())
+        _lib.check(rc, "sss_gat_aggregate")
+
+    # ------------------------------------------------------------------ forward
+    def _features(self, store, table, n):
+        feat = getattr(store, "feat", None)
+        W = self.cfg.node_width
+        buf = torch.empty((n, W), dtype=torch.float32, device=self.device)
+        if feat is not None:
+            buf[:, :self.cfg.d_in] = feat.to(self.device, torch.float32)
+        else:
+            if table is None:
+                raise _lib.SssError("no feature table in the weights and no .feat on the batch")
+            ids = store.x.to(self.device, torch.int64).contiguous()
+            rc = _lib.lib().sss_gather_rows(table.data_ptr(), ids.data_ptr(), n, self.cfg.d_in,
+                                            buf.data_ptr(), buf.stride(0), self._st())
+            _lib.check(rc, "sss_gather_rows")
+        return buf
+
+    @torch.no_grad()
+    def forward(self, data, query_node_mask=None, product_node_mask=None, get_node=False, get_token=False):
+        cfg, L, dev = self.cfg, _lib.lib(), self.device
+        h, D, P, W = cfg.h, cfg.d_out, cfg.max_seq_len, cfg.node_width
+        q, p = data["query"], data["product"]
+        q_batch = q.batch.to(dev, torch.int64).contiguous()
+        p_batch = p.batch.to(dev, torch.int64).contiguous()
+        Nq, Np = int(q_batch.shape[0]), int(p_batch.shape[0])
+        B = int(getattr(data, "num_graphs", 0)) or int(max(q_batch.max().item(), p_batch.max().item()) + 1)
+
+        NQ = self._features(q, self.query_table, Nq)      # [Nq, W]; slice 0 = input features
+        NP = self._features(p, self.item_table, Np)       # embedding lookup (NodeAsinEmbedding)
+        if query_node_mask is not None:                   # model/model.py:293-296 (None at inference)
+            NQ[:, :cfg.d_in] *= query_node_mask.to(dev, torch.float32).view(-1, 1)
+        if product_node_mask is not None:
+            NP[:, :cfg.d_in] *= product_node_mask.to(dev, torch.float32).view(-1, 1)
+        if self.debug_nan_checks and (torch.isnan(NQ[:, :cfg.d_in]).any() or torch.isnan(NP[:, :cfg.d_in]).any()):
+            raise RuntimeError("nan in embedding[query]")   # model/model.py:312
+
+        ei = data.edge_index_dict
+        loops = cfg.self_loop_rule == "pyg_bipartite_global"
+        ei_qp, ei_pq, ei_pp = (ei[k].to(dev, torch.int64) for k in (EDGE_QP, EDGE_PQ, EDGE_PP))
+        csr_qp = build_csr(ei_qp, Np, Nq, loops)          # targets = products
+        csr_pq = build_csr(ei_pq, Nq, Np, loops)          # targets = queries
+        ew = None
+        if self.use_edge_weight:
+            ew = data.edge_weight_dict[EDGE_PP].to(dev, torch.float32)
+        csr_pp = build_csr(ei_pp, Np, Np, False, ew)
+
+        mp, mq = 5 * h + ALPHA_PAD, h + ALPHA_PAD
+        Yp = torch.empty((Np, mp), dtype=torch.float32, device=dev)
+        Yq = torch.empty((Nq, mq), dtype=torch.float32, device=dev)
+        T1 = torch.empty((Np, h), dtype=torch.float32, device=dev)
+        T2 = torch.empty((Np, h), dtype=torch.float32, device=dev)
+        T3 = torch.empty((Np, 3 * h), dtype=torch.float32, device=dev)
+        for l, lw in enumerate(self.layers):
+            off = 0 if l == 0 else cfg.d_in + (l - 1) * h
+            din = lw["din"]
+            xin_p, xin_q = NP[:, off:off + din], NQ[:, off:off + din]
+            out_p = NP[:, cfg.d_in + l * h: cfg.d_in + (l + 1) * h]
+            out_q = NQ[:, cfg.d_in + l * h: cfg.d_in + (l + 1) * h]
+            self._linear(xin_p, lw["wp"], lw["bp"], Np, mp, din, Yp)
+            self._linear(xin_q, lw["wq"], None, Nq, mq, din, Yq)
+            # products <- queries (GAT) ; products <- products (GGC) ; GRU + sum + relu
+            self._gat(Yq[:, :h], Yq[:, h], Yp[:, 5 * h + 1], csr_qp, Np, lw["bias_qp"], 0, T1)
+            rowptr, col, wv = csr_pp
+            rc = L.sss_csr_weighted_sum(Yp[:, h:2 * h].data_ptr(), Yp.stride(0), rowptr.data_ptr(), col.data_ptr(),
+                                        0 if wv is None else wv.data_ptr(), Np, h, T2.data_ptr(), T2.stride(0),
+                                        self._st())
+            _lib.check(rc, "sss_csr_weighted_sum")
+            self._linear(T2, lw["w_ih"], lw["b_ih"], Np, 3 * h, h, T3)
+            rc = L.sss_gru_combine(T3.data_ptr(), T3.stride(0), Yp[:, 2 * h:].data_ptr(), Yp.stride(0),
+                                   xin_p.data_ptr(), NP.stride(0), din, T1.data_ptr(), T1.stride(0), Np, h,
+                                   out_p.data_ptr(), NP.stride(0), self._st())
+            _lib.check(rc, "sss_gru_combine")
+            # queries <- products (GAT) + relu
+            self._gat(Yp[:, :h], Yp[:, 5 * h], Yq[:, h + 1], csr_pq, Nq, lw["bias_pq"], 1, out_q)
+        if self.debug_nan_checks and (torch.isnan(NQ).any() or torch.isnan(NP).any()):
+            raise RuntimeError("nan in node embedding")
+
+        # ---- PositionalAttentionPooling (model/gnn.py:193-217)
+        pw = self.pool
+        Dl = D - P
+        ldl = (Dl + 3) // 4 * 4
+        lin_q = torch.empty((Nq, ldl), dtype=torch.float32, device=dev)
+        lin_p = torch.empty((Np, ldl), dtype=torch.float32, device=dev)
+        self._linear(NQ, pw["wq"], pw["bq"], Nq, Dl, W, lin_q)
+        self._linear(NP, pw["wp"], pw["bp"], Np, Dl, W, lin_p)
+        cnt = p.cnt.to(dev, torch.int64)
+        src_p = torch.repeat_interleave(torch.arange(Np, device=dev, dtype=torch.int64), cnt)
+        n_clicks = int(src_p.shape[0])
+        src_row = torch.cat([src_p, torch.arange(Nq, device=dev, dtype=torch.int64)]).to(torch.int32).contiguous()
+        pos_id = torch.cat([p.pos_emb_id.to(dev, torch.int64), q.pos_emb_id.to(dev, torch.int64)]) \
+            .to(torch.int32).contiguous()
+        n_exp = n_clicks + Nq
+        if int(pos_id.shape[0]) != n_exp:
+            raise _lib.SssError("product pos_emb_id must have sum(cnt) entries")
+        node = torch.empty((n_exp, D), dtype=torch.float32, device=dev)
+        rc = L.sss_pool_expand(lin_p.data_ptr(), lin_q.data_ptr(), ldl, src_row.data_ptr(), pos_id.data_ptr(),
+                               n_clicks, n_exp, Dl, P, pw["pos"].data_ptr(), node.data_ptr(), node.stride(0),
+                               self._st())
+        _lib.check(rc, "sss_pool_expand")
+        A = self._linear(node, pw["wn"], pw["bn"], n_exp, D, D)
+        click_batch = p_batch[src_p].contiguous()
+        pptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        qptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        _lib.check(L.sss_segment_ptr(click_batch.data_ptr(), n_clicks, B, pptr.data_ptr(), self._st()), "sss_segment_ptr")
+        _lib.check(L.sss_segment_ptr(q_batch.data_ptr(), Nq, B, qptr.data_ptr(), self._st()), "sss_segment_ptr")
+        coarse = torch.empty((B, D), dtype=torch.float32, device=dev)
+        rc = L.sss_segment_pool(node.data_ptr(), node.stride(0), pptr.data_ptr(), qptr.data_ptr(), n_clicks, B, D,
+                                0, 0, 0, 0, 0, coarse.data_ptr(), coarse.stride(0), self._st())
+        _lib.check(rc, "sss_segment_pool(mean)")
+        Bc = self._linear(coarse, pw["wc"], None, B, D, D)
+        out = torch.empty((B, D), dtype=torch.float32, device=dev)
+        rc = L.sss_segment_pool(node.data_ptr(), node.stride(0), pptr.data_ptr(), qptr.data_ptr(), n_clicks, B, D,
+                                A.data_ptr(), A.stride(0), Bc.data_ptr(), Bc.stride(0), pw["watt"].data_ptr(),
+                                out.data_ptr(), out.stride(0), self._st())
+        _lib.check(rc, "sss_segment_pool(att)")
+
+        node_embedding = {"query": NQ, "product": NP}
+        session_level_token_emb = {}            # the cross-attention branch is commented out upstream
+        if not get_node and not get_token:
+            return out
+        if get_node and not get_token:
+            return out, node_embedding
+        if get_token and not get_node:
+            return out, session_level_token_emb
+        return out, node_embedding, session_level_token_emb
