@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: session queries/sec + recall@10, 1M-session corpus, d=128.
+
+One "step" = one pass of the hot path over one batch of 1024 synthetic query sessions that are
+already resident in HBM as a batched graph: GNN embed (gather -> HeteroGGNN x2 ->
+positional-attention pooling) -> L2-normalise -> fused MFMA scoring + top-10 against this
+rank's corpus shard -> (N > 1) RCCL all-gather of the packed per-shard results -> merge.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Scaling is STRONG: the corpus (1M sessions by default) is fixed and row-sharded over the N
+ranks; `value` = queries / second of the whole job (every rank ends up with the merged result).
+The corpus itself is built before the timed region by embedding synthetic sessions with the
+same encoder (index build; not timed, as in the reference where the index is built once).
+
+Extra JSON objects (see DESIGN.md "measurement"):
+  roofline     -- dominant kernel k_ip_topk_f32<128>: algorithmic FLOPs per launch / its mean
+                  duration, hipEvent-timed on its own stream inside the timed region.
+  cpu_baseline -- the oracle's restatement of the reference CPU path (torch CPU encoder +
+                  faiss-shaped blocked SGEMM/top-k search) on this host's cores, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from sessionsimilaritysearch_amd import _lib  # noqa: E402
+from sessionsimilaritysearch_amd import sessions as S  # noqa: E402
+from sessionsimilaritysearch_amd.distributed import HipEngine, ShardedFlatIndex, shard_range  # noqa: E402
+from sessionsimilaritysearch_amd.encoder import EncoderConfig, SessionEncoder, init_weights  # noqa: E402
+from sessionsimilaritysearch_amd.index import FlatIndex, normalize_  # noqa: E402
+
+CONFIG_INDEX = 2                 # seeds: SURVEY.md 8(d) (20260000 + config index, 1234 + config index)
+BLOCK = 32768                    # sessions generated / embedded per block (seeded per block)
+FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense f32 matrix peak
+
+
+def log(rank, *a):
+    if rank == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def build_corpus_shard(enc, cfg, n_total, lo, hi, device, source):
+    """Normalised session vectors of rows [lo, hi) of the corpus, on device."""
+    out = torch.empty((hi - lo, cfg.d_out), dtype=torch.float32, device=device)
+    if source == "random":          # config C4-style scoring corpus: N(0,1) rows, generated on device
+        g = torch.Generator(device=device)
+        for b0 in range(lo - lo % BLOCK, hi, BLOCK):
+            g.manual_seed(20260000 + CONFIG_INDEX * 100000 + b0 // BLOCK)
+            blk = torch.randn((BLOCK, cfg.d_out), device=device, generator=g)
+            a, b = max(lo, b0), min(hi, b0 + BLOCK, n_total)
+            out[a - lo:b - lo] = blk[a - b0:b - b0]
+        normalize_(out)
+        return out
+    for b0 in range(lo - lo % BLOCK, hi, BLOCK):
+        nb = min(BLOCK, n_total - b0)
+        acts = S.synthetic_actions(nb, 20260000 + CONFIG_INDEX * 100000 + b0 // BLOCK, cfg.n_items, cfg.n_query)
+        a, b = max(lo, b0), min(hi, b0 + nb)
+        if a > b0 or b < b0 + nb:
+            acts = acts.slice(a - b0, b - b0)
+        emb = enc(S.build_batch(acts).to(device))
+        out[a - lo:b - lo] = emb
+    normalize_(out)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--corpus-rows", type=int, default=1_000_000)
+    ap.add_argument("--corpus-source", choices=["sessions", "random"], default="sessions")
+    ap.add_argument("--nq", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--recall-queries", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+
+    L = _lib.lib()
+    d, k, nq, n_total = 128, args.k, args.nq, args.corpus_rows
+    cfg = EncoderConfig(d_in=d, h=d, n_layers=2, d_out=d, self_loop_rule="none")
+    weights = init_weights(cfg, 1234 + CONFIG_INDEX)
+    enc = SessionEncoder(cfg, weights, device).eval()
+
+    # ---- index build (not timed): this rank's rows of the corpus
+    lo, hi = shard_range(n_total, world, rank)
+    t0 = time.time()
+    xb = build_corpus_shard(enc, cfg, n_total, lo, hi, device, args.corpus_source)
+    torch.cuda.synchronize()
+    log(rank, f"corpus shard rows [{lo},{hi}) built in {time.time() - t0:.1f}s")
+    index = FlatIndex(d, "ip", device).adopt(xb, id_offset=lo)
+    index.corpus_max_norm()
+    sharded = ShardedFlatIndex(HipEngine(index), device)
+
+    # ---- query batch, resident in HBM
+    q_acts = S.synthetic_actions(nq, 20269999, cfg.n_items, cfg.n_query)
+    q_host = S.build_batch(q_acts)
+    qbatch = q_host.to(device)
+
+    def step():
+        emb = enc(qbatch)
+        normalize_(emb)
+        return (emb,) + tuple(sharded.search_async(emb, k))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.check(L.sss_profile_enable(1), "profile_enable")
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        emb, D, I, status = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    tot_ms, launches = ctypes.c_double(0), ctypes.c_int(0)
+    _lib.check(L.sss_profile_read(ctypes.byref(tot_ms), ctypes.byref(launches)), "profile_read")
+    L.sss_profile_enable(0)
+    kern_ms = tot_ms.value / max(1, launches.value)
+    flop_per_launch = 2.0 * nq * (hi - lo) * d                 # 2*d FLOP per (query, corpus row) pair
+    achieved = flop_per_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+
+    # ---- stage breakdown (outside the timed region)
+    def timed(fn, n=5):
+        torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    embed_ms = timed(lambda: normalize_(enc(qbatch)))
+    search_ms = timed(lambda: sharded.search_async(emb, k))
+
+    # ---- exactness: unproven count + recall@10 / id equality against the oracle
+    unproven = int(status.sum().item())
+    if world > 1:
+        t = torch.tensor([unproven], dtype=torch.int64, device=device)
+        dist.all_reduce(t)
+        unproven = int(t.item())
+    from oracle import search_ref as sr, gnn_ref       # checker + CPU baseline only
+    nrq = min(args.recall_queries, nq)
+    q_np = emb[:nrq].cpu().numpy()
+    Dl, Il = sr.search_exact(q_np, xb.cpu().numpy(), k, id_offset=lo)
+    if world > 1:
+        pack = torch.cat([torch.from_numpy(Il).to(device).double(), torch.from_numpy(Dl).to(device).double()], 1)
+        allp = [torch.empty_like(pack) for _ in range(world)]
+        dist.all_gather(allp, pack)
+        Ds = [p[:, k:].float().cpu().numpy() for p in allp]
+        Is = [p[:, :k].long().cpu().numpy() for p in allp]
+        Dr, Ir = sr.merge_topk(Ds, Is, k)
+    else:
+        Dr, Ir = Dl, Il
+    I_got, D_got = I[:nrq].cpu().numpy(), D[:nrq].cpu().numpy()
+    recall = sr.recall_at_k(I_got, Ir, k)
+    ids_exact = bool(np.array_equal(I_got, Ir))
+    score_err = float(np.abs(D_got - Dr).max())
+
+    # ---- CPU baseline (rank 0, N = 1): the reference path restated on the host cores
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        corpus_cpu = xb.cpu().numpy()
+        qb_cpu = q_host.to_torch("cpu")
+
+        def cpu_step():
+            e = gnn_ref.encoder_forward(qb_cpu, weights, cfg.n_layers, self_loops=False).numpy()
+            return sr.search_fp32_blocked(sr.normalize(e), corpus_cpu, k, threads=cores)
+        cpu_step()
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t0 < 10 and reps < 20):
+            cpu_step(); reps += 1
+        cpu_s = (time.perf_counter() - t0) / reps
+        cpu = {"value": round(nq / cpu_s, 1), "unit": "queries/s", "cores": cores, "kind": "port",
+               "sample": f"full workload: {nq} query sessions x {n_total} corpus rows, {reps} steps, "
+                         "torch-CPU oracle encoder + blocked float32 SGEMM/top-k (faiss-shaped)"}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        line = {
+            "metric": "session queries/sec", "value": round(nq * args.steps / elapsed, 1), "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{n_total}-session corpus d=128 ({args.corpus_source}), GNN embed (2-layer "
+                                   f"HeteroGGNN + positional-attention pooling) + cosine top-{k}, query batch {nq}",
+                       "corpus_rows": n_total, "rows_per_gpu": hi - lo, "d": d, "k": k, "query_batch": nq,
+                       "parallelism": f"corpus row-sharded x{world}, 1 all-gather + merge" if world > 1 else "single GPU"},
+            "recall_at_10": round(recall, 6), "ids_bit_exact": ids_exact, "max_score_err": score_err,
+            "recall_queries_checked": nrq, "unproven_queries": unproven,
+            "stage_ms": {"embed_normalize": round(embed_ms, 4), "score_topk_merge": round(search_ms, 4)},
+            "roofline": {"bound": "mfma", "kernel": "k_ip_topk_f32<128>", "achieved": round(achieved, 2),
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel_ms": round(kern_ms, 4), "launches": launches.value,
+                         "flop_per_launch": flop_per_launch},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,9 +63,17 @@ int sss_ip_topk_exhaustive(const float* q, const int32_t* qsel, int64_t nsel, co
                            int64_t* I_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- multi-GPU: merge per-shard results after the all-gather (no reference equivalent; the
- * reference is single process).  D_in/I_in [shards, nq, k] -> D_out/I_out [nq, k]. */
-int sss_topk_merge(const float* D_in, const int64_t* I_in, int shards, int64_t nq, int k,
-                   float* D_out, int64_t* I_out, void* stream);
+ * reference is single process).  Shard s's [nq, k] block starts at D_in + s * d_shard_stride
+ * (floats) / I_in + s * i_shard_stride (int64s); output [nq, k] by (score desc, id asc). */
+int sss_topk_merge(const float* D_in, int64_t d_shard_stride, const int64_t* I_in, int64_t i_shard_stride,
+                   int shards, int64_t nq, int k, float* D_out, int64_t* I_out, void* stream);
+
+/* ---- measurement aid (bench.py roofline leg): when enabled, every launch of the dominant
+ * scoring kernel inside sss_ip_topk is bracketed by a hipEvent pair on its own stream;
+ * sss_profile_read synchronises them and returns the summed duration and the launch count
+ * since the last read (process-global, at most 512 launches between reads). */
+int sss_profile_enable(int on);
+int sss_profile_read(double* total_ms, int* launches);
 
 /* ---- (i) encoder pieces.  NodeAsinEmbedding.forward -- model/NodeEmbedding.py:137-138:
  * out[i, :] = table[ids[i], :]; out row stride ld_out floats (writes slice 0 of the node buffer). */

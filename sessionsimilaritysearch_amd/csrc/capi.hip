@@ -29,7 +29,9 @@ int check_launch(const char* what) {
 size_t ip_topk_workspace_bytes(long nq, long n, int d, int k);
 int ip_topk_f32(const float*, long, const float*, long, int, int, long, float, float*, long*, int*, void*,
                 size_t, hipStream_t);
-int topk_merge(const float*, const long*, int, long, int, float*, long*, hipStream_t);
+int topk_merge(const float*, long, const long*, long, int, long, int, float*, long*, hipStream_t);
+int profile_enable(int);
+int profile_read(double*, int*);
 size_t ip_topk_exhaustive_workspace_bytes(long nsel, long n);
 int ip_topk_exhaustive(const float*, const int*, long, const float*, long, int, int, long, int, float*, long*,
                        void*, size_t, hipStream_t);
@@ -81,11 +83,13 @@ int sss_ip_topk_exhaustive(const float* q, const int32_t* qsel, int64_t nsel, co
     return sss::ip_topk_exhaustive(q, qsel, nsel, corpus, n, d, k, id_offset, metric, D_out,
                                    reinterpret_cast<long*>(I_out), workspace, workspace_bytes, ST(stream));
 }
-int sss_topk_merge(const float* D_in, const int64_t* I_in, int shards, int64_t nq, int k, float* D_out,
-                   int64_t* I_out, void* stream) {
-    return sss::topk_merge(D_in, reinterpret_cast<const long*>(I_in), shards, nq, k, D_out,
-                           reinterpret_cast<long*>(I_out), ST(stream));
+int sss_topk_merge(const float* D_in, int64_t d_shard_stride, const int64_t* I_in, int64_t i_shard_stride,
+                   int shards, int64_t nq, int k, float* D_out, int64_t* I_out, void* stream) {
+    return sss::topk_merge(D_in, d_shard_stride, reinterpret_cast<const long*>(I_in), i_shard_stride, shards, nq,
+                           k, D_out, reinterpret_cast<long*>(I_out), ST(stream));
 }
+int sss_profile_enable(int on) { return sss::profile_enable(on); }
+int sss_profile_read(double* total_ms, int* launches) { return sss::profile_read(total_ms, launches); }
 int sss_gather_rows(const float* table, const int64_t* ids, int64_t n, int d, float* out, int64_t ld_out,
                     void* stream) {
     return sss::gather_rows(table, reinterpret_cast<const long*>(ids), n, d, out, ld_out, ST(stream));

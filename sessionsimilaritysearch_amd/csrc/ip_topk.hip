@@ -448,8 +448,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_rescore(
 // --------------------------------------------------------------------------------------------
 // k-way merge of per-shard results (after the RCCL all-gather): [shards][nq][k] -> [nq][k] by
 // (score desc, id asc); ids < 0 are padding.  One thread per query (k*shards is tiny).
-__global__ void k_topk_merge(const float* __restrict__ D_in, const long* __restrict__ I_in,
-                             int shards, int nq, int k, float* __restrict__ D_out,
+__global__ void k_topk_merge(const float* __restrict__ D_in, long d_stride, const long* __restrict__ I_in,
+                             long i_stride, int shards, int nq, int k, float* __restrict__ D_out,
                              long* __restrict__ I_out) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
@@ -459,10 +459,10 @@ __global__ void k_topk_merge(const float* __restrict__ D_in, const long* __restr
         int bs = -1; float bd = 0.f; long bi = 0;
         for (int s = 0; s < shards; ++s) {
             if (pos[s] >= k) continue;
-            const size_t a = ((size_t)s * nq + q) * k + pos[s];
-            const long id = I_in[a];
+            const size_t a = (size_t)q * k + pos[s];
+            const long id = I_in[(size_t)s * i_stride + a];
             if (id < 0) { pos[s] = k; continue; }
-            const float dd = D_in[a];
+            const float dd = D_in[(size_t)s * d_stride + a];
             if (bs < 0 || dd > bd || (dd == bd && id < bi)) { bs = s; bd = dd; bi = id; }
         }
         if (bs < 0) { D_out[(size_t)q * k + o] = -3.4028234663852886e38f; I_out[(size_t)q * k + o] = -1; }
@@ -471,6 +471,43 @@ __global__ void k_topk_merge(const float* __restrict__ D_in, const long* __restr
 }
 
 // ------------------------------------------------------------------------------ host launchers
+// Optional timing of the dominant kernel (bench.py roofline leg): when enabled, every main-pass
+// scan launch is bracketed by a hipEvent pair on ITS stream; profile_read() drains the ring.
+namespace {
+constexpr int PROF_RING = 512;
+struct Prof {
+    bool on = false;
+    int n = 0;
+    hipEvent_t ev[2 * PROF_RING];
+    bool made = false;
+} g_prof;
+}  // namespace
+
+int profile_enable(int on) {
+    if (on && !g_prof.made) {
+        for (int i = 0; i < 2 * PROF_RING; ++i)
+            if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) { set_error("profile_enable: hipEventCreate failed"); return SSS_EHIP; }
+        g_prof.made = true;
+    }
+    g_prof.on = on != 0;
+    g_prof.n = 0;
+    return SSS_OK;
+}
+
+int profile_read(double* total_ms, int* launches) {
+    double sum = 0.0;
+    for (int i = 0; i < g_prof.n; ++i) {
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) { set_error("profile_read: sync failed"); return SSS_EHIP; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) { set_error("profile_read: elapsed failed"); return SSS_EHIP; }
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = g_prof.n;
+    g_prof.n = 0;
+    return SSS_OK;
+}
+
 static int pick_splits(long n, int G) {
     // S*G workgroups, one per CU (256 CUs); S a multiple of 8 (XCD remap); >= 64 rows a split.
     int S = (256 / G) & ~7;
@@ -568,7 +605,10 @@ int ip_topk_f32(const float* q, long nq, const float* c, long n, int d, int k, l
         if (rc) return rc;
     }
     const float* tau_in = p.pre_tiles > 0 ? tau : nullptr;
+    const bool prof = g_prof.on && g_prof.n < PROF_RING;
+    if (prof) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
     rc = scan_dispatch(d, q, (int)nq, c, (int)n, p, false, tau_in, cs, ci, st);
+    if (prof) { (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st); ++g_prof.n; }
     if (rc) return rc;
     const size_t lds = key_lds + SEL_MAX_K2 * 16 + (size_t)d * 4 + (size_t)p.K2 * (d + 4) * 4;
     static bool attr_done = false;
@@ -582,11 +622,14 @@ int ip_topk_f32(const float* q, long nq, const float* c, long n, int d, int k, l
     return check_launch("k_select_rescore");
 }
 
-int topk_merge(const float* D_in, const long* I_in, int shards, long nq, int k, float* D_out,
-               long* I_out, hipStream_t st) {
-    if (shards < 1 || shards > 64 || nq <= 0 || k <= 0) { set_error("topk_merge: bad arguments"); return SSS_EINVAL; }
-    hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, st, D_in, I_in, shards,
-                       (int)nq, k, D_out, I_out);
+int topk_merge(const float* D_in, long d_stride, const long* I_in, long i_stride, int shards, long nq, int k,
+               float* D_out, long* I_out, hipStream_t st) {
+    if (shards < 1 || shards > 64 || nq <= 0 || k <= 0 || d_stride < nq * k || i_stride < nq * k) {
+        set_error("topk_merge: bad arguments");
+        return SSS_EINVAL;
+    }
+    hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, st, D_in, d_stride, I_in,
+                       i_stride, shards, (int)nq, k, D_out, I_out);
     return check_launch("k_topk_merge");
 }
 

@@ -1,0 +1,104 @@
+"""Row-sharded flat index over the GPUs of one node: one process per GPU, the normalised corpus
+split by rows, per-shard exact top-k, ONE all-gather of the packed (ids | scores) block over
+RCCL/xGMI, then a k-way merge on every rank.
+
+The reference is single-process (no NCCL/MPI call site anywhere); this is the one parallel
+strategy the path needs, and the only collective is that all-gather of ``12 * nq * k`` bytes per
+rank -- latency-bound, so it is a single ``all_gather_into_tensor`` rather than a ring of
+small messages.  Queries are replicated (every rank embeds the same query batch; cheaper than a
+broadcast + sync at 512 KB).
+
+The local search and the merge are injected (``engine``) so the sharding / packing / gather
+logic can be exercised on CPU with the ``gloo`` backend in the tests; the default engine is the
+HIP one and has no CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, world: int, rank: int):
+    """Contiguous row range of ``rank``: sizes differ by at most one row, earlier ranks larger."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class HipEngine:
+    """Local fused search + merge through libsss (the product engine)."""
+
+    def __init__(self, index):
+        self.index = index
+
+    def local_search(self, q, k, D, I, status):
+        self.index.search_fused(q, k, (D, I, status))
+
+    def fix_unproven(self, q, k, D, I, status):
+        bad = torch.nonzero(status).flatten()
+        if bad.numel():
+            self.index.search_exhaustive(q, k, D, I, bad)
+        return int(bad.numel())
+
+    def merge(self, pack_all, chunk, shards, nq, k, D_out, I_out):
+        from . import _lib
+        i_ptr = pack_all.data_ptr()
+        d_ptr = i_ptr + nq * k * 8
+        rc = _lib.lib().sss_topk_merge(d_ptr, 2 * chunk, i_ptr, chunk, shards, nq, k, D_out.data_ptr(),
+                                       I_out.data_ptr(), _lib.stream_ptr(pack_all.device))
+        _lib.check(rc, "sss_topk_merge")
+
+
+class ShardedFlatIndex:
+    """``index.search(q, k)`` over a corpus row-sharded across ``dist`` ranks.
+
+    ``engine.local_search`` must write this rank's exact top-k with GLOBAL ids (id_offset =
+    first row of the shard).  Every rank returns the full merged result.
+    """
+
+    def __init__(self, engine, device, group=None):
+        self.engine = engine
+        self.device = device
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._bufs = {}
+
+    def _buffers(self, nq, k):
+        key = (nq, k)
+        if key not in self._bufs:
+            nk = nq * k
+            chunk = nk + (nk + 1) // 2                       # int64 words: ids, then float32 scores
+            pack = torch.zeros(chunk, dtype=torch.int64, device=self.device)
+            pack_all = torch.zeros(self.world * chunk, dtype=torch.int64, device=self.device)
+            I = pack[:nk].view(nq, k)
+            D = pack[nk:].view(torch.float32)[:nk].view(nq, k)
+            status = torch.zeros(nq, dtype=torch.int32, device=self.device)
+            Do = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            Io = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+            self._bufs[key] = (chunk, pack, pack_all, D, I, status, Do, Io)
+        return self._bufs[key]
+
+    def search_async(self, q, k):
+        """Enqueue local search -> all-gather -> merge; no host sync.  Returns (D, I, status):
+        status is this rank's per-query "proven exact" vector (0 = proven)."""
+        nq = q.shape[0]
+        chunk, pack, pack_all, D, I, status, Do, Io = self._buffers(nq, k)
+        self.engine.local_search(q, k, D, I, status)
+        if self.world == 1:
+            return D, I, status
+        dist.all_gather_into_tensor(pack_all, pack, group=self.group)
+        self.engine.merge(pack_all, chunk, self.world, nq, k, Do, Io)
+        return Do, Io, status
+
+    def search(self, q, k):
+        """Exact search: re-runs locally unproven queries exhaustively before the exchange."""
+        nq = q.shape[0]
+        chunk, pack, pack_all, D, I, status, Do, Io = self._buffers(nq, k)
+        self.engine.local_search(q, k, D, I, status)
+        self.engine.fix_unproven(q, k, D, I, status)
+        if self.world == 1:
+            return D, I
+        dist.all_gather_into_tensor(pack_all, pack, group=self.group)
+        self.engine.merge(pack_all, chunk, self.world, nq, k, Do, Io)
+        return Do, Io

@@ -187,7 +187,7 @@ def test_shard_merge_equals_single_index(cuda):
             Ds.append(D); Is.append(I)
         Din, Iin = torch.stack(Ds).contiguous(), torch.stack(Is).contiguous()
         Dm = torch.empty_like(Ds[0]); Im = torch.empty_like(Is[0])
-        rc = _lib.lib().sss_topk_merge(Din.data_ptr(), Iin.data_ptr(), shards, 100, 10, Dm.data_ptr(),
+        rc = _lib.lib().sss_topk_merge(Din.data_ptr(), 1000, Iin.data_ptr(), 1000, shards, 100, 10, Dm.data_ptr(),
                                        Im.data_ptr(), _lib.stream_ptr(cuda))
         _lib.check(rc, "merge")
         assert np.array_equal(Im.cpu().numpy(), Ir) and np.array_equal(Dm.cpu().numpy(), Dr)
