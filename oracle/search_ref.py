@@ -113,7 +113,7 @@ def search_exact(q, c, k, id_offset=0, threads=0):
 
 
 # ------------------------------------------------------- faiss-shaped fp32 search (CPU baseline)
-def search_fp32_blocked(q, c, k, block=65536, threads=None):
+def search_fp32_blocked(q, c, k, block=16384, threads=None):
     """What the reference's CPU path does inside ``IndexFlatIP.search``
     (test_amazon_filterd.py:578; Appendix A.5): blocked float32 SGEMM over corpus chunks,
     per-query top-k per chunk, running merge.  float32 BLAS summation order, so near-ties

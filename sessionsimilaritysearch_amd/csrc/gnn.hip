@@ -17,99 +17,78 @@
 namespace sss {
 
 // ------------------------------------------------------------------------------------------
-// Y[N, M] = X[N, K] * W[M, K]^T (+ bias[M]).  128 x 128 block tile, 4 waves of 64 x 64
-// (2 x 2 MFMA tiles), K staged through LDS in chunks of 32 (register-staged, split
-// issue-early / write-late), 16-byte chunk XOR swizzle -> conflict-free ds_read_b128.
-constexpr int LB_M = 128, LB_N = 128, LB_K = 32;
+// Y[N, M] = X[N, K] * W[M, K]^T (+ bias[M]).  64 x 64 block tile, 4 waves of 32 x 32 (one MFMA
+// tile each), K consumed in chunks of up to 128 staged ONCE per chunk through LDS (register
+// staged, 16 float4 loads in flight per thread), 16-byte chunk XOR swizzle -> conflict-free
+// ds_read_b128.  The encoder's shapes are K = 64..384 with a few thousand rows per query batch:
+// per-workgroup latency, not FLOPs, bounds them, so the K loop is 1-3 steps and two workgroups
+// share a CU (64 KiB LDS each).
+constexpr int LT = 64;      // tile rows (X) and columns (W rows)
+constexpr int LKC = 128;    // K chunk
 
-__global__ __launch_bounds__(256) void k_linear_f32(const float* __restrict__ X, long ldx,
-                                                    const float* __restrict__ W, long ldw,
-                                                    const float* __restrict__ bias, float* __restrict__ Y,
-                                                    long ldy, long N, int M, int K) {
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];        // [buf][X|W][128*32]
-    float (*lds)[2][LB_N * LB_K] = reinterpret_cast<float (*)[2][LB_N * LB_K]>(lds_raw);
+__global__ __launch_bounds__(256, 2) void k_linear_f32(const float* __restrict__ X, long ldx,
+                                                       const float* __restrict__ W, long ldw,
+                                                       const float* __restrict__ bias, float* __restrict__ Y,
+                                                       long ldy, long N, int M, int K) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];        // [X|W][64 rows][128]
+    float* lx = lds_raw;
+    float* lw = lds_raw + LT * LKC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const long row0 = (long)blockIdx.x * LB_N;
-    const int col0 = blockIdx.y * LB_M;
+    const long row0 = (long)blockIdx.x * LT;
+    const int col0 = blockIdx.y * LT;
 
-    // staging: 128 rows x 8 chunks = 1024 float4 per operand tile, 4 per thread
-    float4 sx[4], sw[4];
-    auto g_load = [&](int k0) {
+    f32x16 acc = {0};
+    for (int k0 = 0; k0 < K; k0 += LKC) {
+        const int kc = K - k0 < LKC ? K - k0 : LKC;        // multiple of 32
+        const int cpr = kc / 4;                              // 16-byte chunks per row (8..32)
+        const int total = LT * cpr;
+        float4 sx[8], sw[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             const int p = tid + 256 * i;
-            const int tr = p >> 3, c = p & 7;
-            long gr = row0 + tr; if (gr > N - 1) gr = N - 1;
-            int gw = col0 + tr; if (gw > M - 1) gw = M - 1;
-            sx[i] = *reinterpret_cast<const float4*>(X + gr * ldx + k0 + c * 4);
-            sw[i] = *reinterpret_cast<const float4*>(W + (long)gw * ldw + k0 + c * 4);
-        }
-    };
-    auto l_store = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = tid + 256 * i;
-            const int tr = p >> 3, c = p & 7;
-            const int cs = c ^ ((tr >> 1) & 7);
-            *reinterpret_cast<float4*>(&lds[buf][0][(tr * 8 + cs) * 4]) = sx[i];
-            *reinterpret_cast<float4*>(&lds[buf][1][(tr * 8 + cs) * 4]) = sw[i];
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x16){0};
-
-    const int nk = K / LB_K;
-    g_load(0);
-    l_store(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) g_load((kt + 1) * LB_K);
-        const float* tx = lds[buf][0];
-        const float* tw = lds[buf][1];
-#pragma unroll
-        for (int u = 0; u < LB_K / 8; ++u) {
-            float4 a[2], b[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int xr = wr * 64 + m * 32 + r;
-                a[m] = *reinterpret_cast<const float4*>(tx + (xr * 8 + ((2 * u + h) ^ ((xr >> 1) & 7))) * 4);
-                const int wrow = wc * 64 + m * 32 + r;
-                b[m] = *reinterpret_cast<const float4*>(tw + (wrow * 8 + ((2 * u + h) ^ ((wrow >> 1) & 7))) * 4);
+            if (p < total) {
+                const int tr = p / cpr, c = p % cpr;
+                long gr = row0 + tr; if (gr > N - 1) gr = N - 1;
+                int gw = col0 + tr; if (gw > M - 1) gw = M - 1;
+                sx[i] = *reinterpret_cast<const float4*>(X + gr * ldx + k0 + c * 4);
+                sw[i] = *reinterpret_cast<const float4*>(W + (long)gw * ldw + k0 + c * 4);
             }
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int nn = 0; nn < 2; ++nn) {
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[nn].x, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[nn].y, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[nn].z, acc[m][nn], 0, 0, 0);
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[nn].w, acc[m][nn], 0, 0, 0);
-                }
         }
-        if (kt + 1 < nk) l_store(buf ^ 1);
+        if (k0 > 0) __syncthreads();                         // previous chunk fully consumed
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = tid + 256 * i;
+            if (p < total) {
+                const int tr = p / cpr, c = p % cpr;
+                const int cs = c ^ (tr & 15);                // rows are 32 chunks apart: stays in the row
+                *reinterpret_cast<float4*>(lx + (tr * 32 + cs) * 4) = sx[i];
+                *reinterpret_cast<float4*>(lw + (tr * 32 + cs) * 4) = sw[i];
+            }
+        }
         __syncthreads();
+        const int xr = wr * 32 + r, wrow = wc * 32 + r;
+        const int nu = kc / 8;
+        for (int u = 0; u < nu; ++u) {
+            const float4 a = *reinterpret_cast<const float4*>(lx + (xr * 32 + ((2 * u + h) ^ (xr & 15))) * 4);
+            const float4 b = *reinterpret_cast<const float4*>(lw + (wrow * 32 + ((2 * u + h) ^ (wrow & 15))) * 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
     }
     // C/D map of 32x32: col = lane & 31 (W row), row = (j & 3) + 8 * (j >> 2) + 4 * h (X row)
+    const int col = col0 + wc * 32 + r;
+    if (col < M) {
+        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn) {
-            const int col = col0 + wc * 64 + nn * 32 + r;
-            if (col >= M) continue;
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const long row = row0 + wr * 64 + m * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-                if (row < N) Y[row * ldy + col] = acc[m][nn][j] + bv;
-            }
+        for (int j = 0; j < 16; ++j) {
+            const long row = row0 + wr * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+            if (row < N) Y[row * ldy + col] = acc[j] + bv;
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -354,13 +333,13 @@ static unsigned grid_rows(long n, int lpr) {
 
 int linear_f32(const float* X, long ldx, const float* W, long ldw, const float* bias, float* Y, long ldy,
                long N, int M, int K, hipStream_t st) {
-    if (N < 0 || M <= 0 || K <= 0 || K % LB_K || ldx % 4 || ldw % 4 || ldx < K || ldw < K || ldy < M) {
+    if (N < 0 || M <= 0 || K <= 0 || K % 32 || ldx % 4 || ldw % 4 || ldx < K || ldw < K || ldy < M) {
         set_error("linear: need K %% 32 == 0, ldx/ldw %% 4 == 0 and >= K, ldy >= M (N=%ld M=%d K=%d)", N, M, K);
         return SSS_EINVAL;
     }
     if (N == 0) return SSS_OK;
-    dim3 grid((unsigned)((N + LB_N - 1) / LB_N), (unsigned)((M + LB_M - 1) / LB_M));
-    const int lds = 2 * 2 * LB_N * LB_K * 4;
+    dim3 grid((unsigned)((N + LT - 1) / LT), (unsigned)((M + LT - 1) / LT));
+    const int lds = 2 * LT * LKC * 4;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_f32),

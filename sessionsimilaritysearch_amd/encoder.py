@@ -134,6 +134,11 @@ def build_csr(edge_index: torch.Tensor, n_dst: int, n_src: int = 0, self_loops: 
     return rowptr, col, wv
 
 
+class PreparedBatch:
+    """Device-resident batch: feature ids + CSR adjacencies + pooling index arrays
+    (``SessionEncoder.prepare``)."""
+
+
 class SessionEncoder:
     """``model.forward(data)`` drop-in (``UnifyPoolingGraphLevelEncoder``).  ``data`` is a
     ``SessionBatch`` (or any object with the same attributes, e.g. a PyG hetero batch whose
@@ -224,9 +229,55 @@ class SessionEncoder:
                                           self._st())
         _lib.check(rc, "sss_gat_aggregate")
 
-    # ------------------------------------------------------------------ forward
-    def _features(self, store, table, n):
-        feat = getattr(store, "feat", None)
+    # ------------------------------------------------------------------ batch preparation
+    @torch.no_grad()
+    def prepare(self, data):
+        """Integer/index side of a batch, computed once and kept resident in HBM with it: the
+        three CSR-by-target adjacencies (PyG self-loop rewrite applied per ``self_loop_rule``),
+        the expanded-node index arrays of the pooling and the per-graph segment pointers.
+        ``forward`` accepts the returned ``PreparedBatch`` and then launches arithmetic kernels
+        only.  (In the reference this structural work is ``sequence_to_graph`` +
+        ``Batch.from_data_list`` on the host, outside the model's forward.)"""
+        if isinstance(data, PreparedBatch):
+            return data
+        cfg, L, dev = self.cfg, _lib.lib(), self.device
+        q, p = data["query"], data["product"]
+        pb = PreparedBatch()
+        pb.q_batch = q.batch.to(dev, torch.int64).contiguous()
+        pb.p_batch = p.batch.to(dev, torch.int64).contiguous()
+        pb.Nq, pb.Np = int(pb.q_batch.shape[0]), int(pb.p_batch.shape[0])
+        pb.B = int(getattr(data, "num_graphs", 0)) or int(max(pb.q_batch.max().item(), pb.p_batch.max().item()) + 1)
+        pb.q_feat = getattr(q, "feat", None)
+        pb.p_feat = getattr(p, "feat", None)
+        pb.q_ids = None if pb.q_feat is not None else q.x.to(dev, torch.int64).contiguous()
+        pb.p_ids = None if pb.p_feat is not None else p.x.to(dev, torch.int64).contiguous()
+        ei = data.edge_index_dict
+        loops = cfg.self_loop_rule == "pyg_bipartite_global"
+        ei_qp, ei_pq, ei_pp = (ei[k].to(dev, torch.int64) for k in (EDGE_QP, EDGE_PQ, EDGE_PP))
+        pb.csr_qp = build_csr(ei_qp, pb.Np, pb.Nq, loops)          # targets = products
+        pb.csr_pq = build_csr(ei_pq, pb.Nq, pb.Np, loops)          # targets = queries
+        ew = None
+        if self.use_edge_weight:
+            ew = data.edge_weight_dict[EDGE_PP].to(dev, torch.float32)
+        pb.csr_pp = build_csr(ei_pp, pb.Np, pb.Np, False, ew)
+        cnt = p.cnt.to(dev, torch.int64)
+        src_p = torch.repeat_interleave(torch.arange(pb.Np, device=dev, dtype=torch.int64), cnt)
+        pb.n_clicks = int(src_p.shape[0])
+        pb.src_row = torch.cat([src_p, torch.arange(pb.Nq, device=dev, dtype=torch.int64)]).to(torch.int32).contiguous()
+        pb.pos_id = torch.cat([p.pos_emb_id.to(dev, torch.int64), q.pos_emb_id.to(dev, torch.int64)]) \
+            .to(torch.int32).contiguous()
+        if int(pb.pos_id.shape[0]) != pb.n_clicks + pb.Nq:
+            raise _lib.SssError("product pos_emb_id must have sum(cnt) entries")
+        if int(pb.pos_id.max().item()) >= cfg.max_seq_len or int(pb.pos_id.min().item()) < 0:
+            raise IndexError("index out of range in self")      # what nn.Embedding raises upstream
+        click_batch = pb.p_batch[src_p].contiguous()
+        pb.pptr = torch.empty(pb.B + 1, dtype=torch.int32, device=dev)
+        pb.qptr = torch.empty(pb.B + 1, dtype=torch.int32, device=dev)
+        _lib.check(L.sss_segment_ptr(click_batch.data_ptr(), pb.n_clicks, pb.B, pb.pptr.data_ptr(), self._st()), "sss_segment_ptr")
+        _lib.check(L.sss_segment_ptr(pb.q_batch.data_ptr(), pb.Nq, pb.B, pb.qptr.data_ptr(), self._st()), "sss_segment_ptr")
+        return pb
+
+    def _features(self, ids, feat, table, n):
         W = self.cfg.node_width
         buf = torch.empty((n, W), dtype=torch.float32, device=self.device)
         if feat is not None:
@@ -234,7 +285,6 @@ class SessionEncoder:
         else:
             if table is None:
                 raise _lib.SssError("no feature table in the weights and no .feat on the batch")
-            ids = store.x.to(self.device, torch.int64).contiguous()
             rc = _lib.lib().sss_gather_rows(table.data_ptr(), ids.data_ptr(), n, self.cfg.d_in,
                                             buf.data_ptr(), buf.stride(0), self._st())
             _lib.check(rc, "sss_gather_rows")
@@ -244,14 +294,11 @@ class SessionEncoder:
     def forward(self, data, query_node_mask=None, product_node_mask=None, get_node=False, get_token=False):
         cfg, L, dev = self.cfg, _lib.lib(), self.device
         h, D, P, W = cfg.h, cfg.d_out, cfg.max_seq_len, cfg.node_width
-        q, p = data["query"], data["product"]
-        q_batch = q.batch.to(dev, torch.int64).contiguous()
-        p_batch = p.batch.to(dev, torch.int64).contiguous()
-        Nq, Np = int(q_batch.shape[0]), int(p_batch.shape[0])
-        B = int(getattr(data, "num_graphs", 0)) or int(max(q_batch.max().item(), p_batch.max().item()) + 1)
+        pb = self.prepare(data)
+        Nq, Np, B = pb.Nq, pb.Np, pb.B
 
-        NQ = self._features(q, self.query_table, Nq)      # [Nq, W]; slice 0 = input features
-        NP = self._features(p, self.item_table, Np)       # embedding lookup (NodeAsinEmbedding)
+        NQ = self._features(pb.q_ids, pb.q_feat, self.query_table, Nq)   # [Nq, W]; slice 0 = input features
+        NP = self._features(pb.p_ids, pb.p_feat, self.item_table, Np)    # embedding lookup (NodeAsinEmbedding)
         if query_node_mask is not None:                   # model/model.py:293-296 (None at inference)
             NQ[:, :cfg.d_in] *= query_node_mask.to(dev, torch.float32).view(-1, 1)
         if product_node_mask is not None:
@@ -259,16 +306,7 @@ class SessionEncoder:
         if self.debug_nan_checks and (torch.isnan(NQ[:, :cfg.d_in]).any() or torch.isnan(NP[:, :cfg.d_in]).any()):
             raise RuntimeError("nan in embedding[query]")   # model/model.py:312
 
-        ei = data.edge_index_dict
-        loops = cfg.self_loop_rule == "pyg_bipartite_global"
-        ei_qp, ei_pq, ei_pp = (ei[k].to(dev, torch.int64) for k in (EDGE_QP, EDGE_PQ, EDGE_PP))
-        csr_qp = build_csr(ei_qp, Np, Nq, loops)          # targets = products
-        csr_pq = build_csr(ei_pq, Nq, Np, loops)          # targets = queries
-        ew = None
-        if self.use_edge_weight:
-            ew = data.edge_weight_dict[EDGE_PP].to(dev, torch.float32)
-        csr_pp = build_csr(ei_pp, Np, Np, False, ew)
-
+        csr_qp, csr_pq, csr_pp = pb.csr_qp, pb.csr_pq, pb.csr_pp
         mp, mq = 5 * h + ALPHA_PAD, h + ALPHA_PAD
         Yp = torch.empty((Np, mp), dtype=torch.float32, device=dev)
         Yq = torch.empty((Nq, mq), dtype=torch.float32, device=dev)
@@ -308,26 +346,14 @@ class SessionEncoder:
         lin_p = torch.empty((Np, ldl), dtype=torch.float32, device=dev)
         self._linear(NQ, pw["wq"], pw["bq"], Nq, Dl, W, lin_q)
         self._linear(NP, pw["wp"], pw["bp"], Np, Dl, W, lin_p)
-        cnt = p.cnt.to(dev, torch.int64)
-        src_p = torch.repeat_interleave(torch.arange(Np, device=dev, dtype=torch.int64), cnt)
-        n_clicks = int(src_p.shape[0])
-        src_row = torch.cat([src_p, torch.arange(Nq, device=dev, dtype=torch.int64)]).to(torch.int32).contiguous()
-        pos_id = torch.cat([p.pos_emb_id.to(dev, torch.int64), q.pos_emb_id.to(dev, torch.int64)]) \
-            .to(torch.int32).contiguous()
-        n_exp = n_clicks + Nq
-        if int(pos_id.shape[0]) != n_exp:
-            raise _lib.SssError("product pos_emb_id must have sum(cnt) entries")
+        n_clicks, n_exp = pb.n_clicks, pb.n_clicks + Nq
         node = torch.empty((n_exp, D), dtype=torch.float32, device=dev)
-        rc = L.sss_pool_expand(lin_p.data_ptr(), lin_q.data_ptr(), ldl, src_row.data_ptr(), pos_id.data_ptr(),
+        rc = L.sss_pool_expand(lin_p.data_ptr(), lin_q.data_ptr(), ldl, pb.src_row.data_ptr(), pb.pos_id.data_ptr(),
                                n_clicks, n_exp, Dl, P, pw["pos"].data_ptr(), node.data_ptr(), node.stride(0),
                                self._st())
         _lib.check(rc, "sss_pool_expand")
         A = self._linear(node, pw["wn"], pw["bn"], n_exp, D, D)
-        click_batch = p_batch[src_p].contiguous()
-        pptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
-        qptr = torch.empty(B + 1, dtype=torch.int32, device=dev)
-        _lib.check(L.sss_segment_ptr(click_batch.data_ptr(), n_clicks, B, pptr.data_ptr(), self._st()), "sss_segment_ptr")
-        _lib.check(L.sss_segment_ptr(q_batch.data_ptr(), Nq, B, qptr.data_ptr(), self._st()), "sss_segment_ptr")
+        pptr, qptr = pb.pptr, pb.qptr
         coarse = torch.empty((B, D), dtype=torch.float32, device=dev)
         rc = L.sss_segment_pool(node.data_ptr(), node.stride(0), pptr.data_ptr(), qptr.data_ptr(), n_clicks, B, D,
                                 0, 0, 0, 0, 0, coarse.data_ptr(), coarse.stride(0), self._st())
