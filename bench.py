@@ -94,12 +94,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # SSS_BENCH_BACKEND=gloo is a REHEARSAL mode for a one-GPU box (ranks share the card, the
+    # all-gather goes through the host); the real multi-GPU run uses RCCL ("nccl" on ROCm).
+    backend = os.environ.get("SSS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     L = _lib.lib()
     d, k, nq, n_total = 128, args.k, args.nq, args.corpus_rows
