@@ -11,7 +11,7 @@ import subprocess
 from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsss.so")
+LIB_PATH = os.environ.get("SSS_LIB_PATH") or os.path.join(_HERE, "libsss.so")   # env override: dev ablation builds
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None

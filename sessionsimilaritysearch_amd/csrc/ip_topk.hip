@@ -22,7 +22,6 @@
 namespace sss {
 
 constexpr int KP = 16;          // per-lane list length (register resident)
-constexpr int TILE_ROWS = 64;   // corpus rows per LDS tile
 constexpr int WG_QUERIES = 256; // queries per workgroup (8 waves x 32)
 
 typedef const float __attribute__((address_space(1)))* gptr_f32;
@@ -49,23 +48,32 @@ __device__ __forceinline__ void list_insert(float (&ls)[N], int (&li)[N], float 
 // PRE = true is the sampled pre-pass: same MFMA stream, but the epilogue only keeps each lane's
 // running maximum; the K2-th largest of a query's 2*S lane maxima (k_tau) is a score that at
 // least K2 distinct corpus rows reach, i.e. a valid admission threshold for the main pass.
+//
+// A tile is TR = 64*H corpus rows (one barrier per tile); a wave walks it in H sub-steps of 64
+// rows (two 32x32 accumulators) with the top-k epilogue after every sub-step.
+template <int D> struct ScanCfg { static constexpr int TR = D <= 128 ? 128 : 64; };
+
 template <int D, bool PRE>
 __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
     const float* __restrict__ Q, int nq, const float* __restrict__ C, int n, int tiles_per_split,
     int total_tiles, int tile_step_rows, int S, int G, const float* __restrict__ tau0,
     float* __restrict__ cand_s, int* __restrict__ cand_i) {
+    constexpr int TR = ScanCfg<D>::TR;
+    constexpr int H = TR / 64;
     constexpr int CH = D / 4;                       // 16-byte chunks per row
-    constexpr int TILE_BYTES = TILE_ROWS * D * 4;
-    constexpr int LOADS_PER_WAVE = CH / 8;          // glds wave-instructions per wave per tile
+    constexpr int TILE_BYTES = TR * D * 4;
+    constexpr int LOADS_PER_WAVE = TR * CH / 64 / 8;  // glds wave-instructions per wave per tile
+    constexpr bool PRECOMP = D <= 128;               // keep the DMA lane offsets in VGPRs (register budget)
+    static_assert(CH <= 64, "row longer than one LDS-DMA instruction");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    // Waves 4-7 are the SIMD partners of waves 0-3.  They run their top-k epilogue one tile
-    // LATE (after the barrier, under the partner's first MFMAs of the next tile) so the two
-    // waves of a SIMD are never both outside their MFMA stream at a tile boundary.
+    // Waves 4-7 are the SIMD partners of waves 0-3.  They run their top-k epilogue one sub-step
+    // LATE (the last one of a tile after the barrier, under the partner's first MFMAs of the
+    // next tile) so the two waves of a SIMD are never both outside their MFMA stream.
     const bool late = wave >= 4;                    // wave-uniform (scalar branch)
 
     // XCD-aware remap: blocks b and b+8 share an XCD (and its L2); the G query groups that
@@ -117,32 +125,50 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
     // asm so hipcc neither counts it nor drains vmcnt(0) at the next ds_read: the next tile
     // stays in flight under this tile's MFMAs and is retired by the explicit vmcnt(0) that
     // precedes the barrier at the end of the iteration (cdna_hip_programming.md section 5.7).
+    // Slot p of the tile (16 B each) holds chunk (p % CH) ^ (row & 15) of row p / CH: the
+    // swizzle is on the SOURCE address, the LDS image is lane-linear.
     const unsigned lds_base = (unsigned)(unsigned long)(lptr_c)smem;
-    auto stage = [&](int buf, int tile_idx) {
-        const long row0 = (long)tile_idx * tile_step_rows;
+    auto slot_row = [&](int i) { return ((wave * LOADS_PER_WAVE + i) * 64 + lane) / CH; };
+    auto slot_off = [&](int i) {                    // byte offset of this lane's chunk inside the tile
+        const int p = (wave * LOADS_PER_WAVE + i) * 64 + lane;
+        const int tr = p / CH, sc = p % CH;
+        return (unsigned)(tr * D * 4 + ((sc ^ (tr & 15)) * 16));
+    };
+    unsigned lane_off[PRECOMP ? LOADS_PER_WAVE : 1];
+    if (PRECOMP) {
 #pragma unroll
-        for (int i = 0; i < LOADS_PER_WAVE; ++i) {
-            const int instr = wave * LOADS_PER_WAVE + i;      // wave-uniform
-            const int p = instr * 64 + lane;                   // 16-byte slot inside the tile
-            const int tr = p / CH, sc = p % CH;
-            const int c = sc ^ (tr & 15);                      // source-side swizzle
-            long grow = row0 + tr;
-            if (grow > (long)n - 1) grow = (long)n - 1;        // clamp; masked in the epilogue
-            const float* src = C + (size_t)grow * D + c * 4;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * TILE_BYTES + instr * 1024);
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        for (int i = 0; i < LOADS_PER_WAVE; ++i) lane_off[i] = slot_off(i);
+    }
+    // One LDS-DMA wave-instruction (piece i of this wave's share of a tile).
+    auto stage_piece = [&](int buf, int tile_idx, int i) {
+        const long row0 = (long)tile_idx * tile_step_rows;
+        const bool inside = row0 + TR <= (long)n;          // wave-uniform
+        const float* tile_src = C + (size_t)row0 * D;       // wave-uniform -> SGPR pair
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            lds_base + buf * TILE_BYTES + (wave * LOADS_PER_WAVE + i) * 1024);
+        unsigned off = PRECOMP ? lane_off[PRECOMP ? i : 0] : slot_off(i);
+        if (!inside) {                                       // ragged last tile: clamp the row
+            const int lr = slot_row(i);
+            long grow = row0 + lr;
+            if (grow > (long)n - 1) grow = (long)n - 1;
+            off = (unsigned)((grow - row0) * D * 4) + (off - (unsigned)(lr * D * 4));
         }
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(dst), "s"(tile_src) : "memory");
+    };
+    auto stage = [&](int buf, int tile_idx) {
+#pragma unroll
+        for (int i = 0; i < LOADS_PER_WAVE; ++i) stage_piece(buf, tile_idx, i);
     };
 
     // per-lane LDS read offset (bytes) of chunk (2u + h) of row r, before the constant part
     const int x = h ^ (r & 15);
     f32x16 acc0 = {0}, acc1 = {0};
 
-    auto mfma_tile = [&](int buf, int next_tile) {
-        const char* tile = smem + buf * TILE_BYTES;
+    auto mfma_sub = [&](int buf, int sub, int next_tile) {
+        const char* tile = smem + buf * TILE_BYTES + sub * (64 * D * 4);
         auto lda = [&](int u, int mb) -> float4 {
             const int c = (2 * u) ^ x;                          // == (2u + h) ^ (r & 15)
             return *reinterpret_cast<const float4*>(tile + ((r + 32 * mb) * CH + c) * 16);
@@ -165,9 +191,13 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, qreg[4 * u + 3], acc1, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             a0 = n0; a1 = n1;
-            // issue the next tile's LDS-DMA under the MFMAs already queued (not at the tile
-            // top, where its address arithmetic would sit between the barrier and MFMA #1)
-            if (u == 1 && next_tile >= 0) { stage(buf ^ 1, next_tile); __builtin_amdgcn_sched_barrier(0); }
+#ifndef SSS_EXP_NO_STAGE
+            // one DMA piece per k-group: each issue hides under the MFMAs this wave just queued
+            if (u >= 1 && u - 1 < LOADS_PER_WAVE && next_tile >= 0) {
+                stage_piece(buf ^ 1, next_tile, u - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
         }
     };
 
@@ -176,55 +206,70 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
     __syncthreads();
 
     // ntiles + 1 iterations: the last one only drains the late waves' deferred epilogue.
+    const int nsub = ntiles * H;
     for (int t = 0; t <= ntiles; ++t) {
         const int buf = t & 1;
-        const int next_tile = t + 1 < ntiles ? tile_lo + t + 1 : -1;
-        if (!late && t < ntiles) mfma_tile(buf, next_tile);
+        for (int sub = 0; sub < H; ++sub) {
+            const int gs = t * H + sub;                        // global sub-step index
+            const int next_tile = (sub == 0 && t + 1 < ntiles) ? tile_lo + t + 1 : -1;
+            if (!late && t < ntiles) mfma_sub(buf, sub, next_tile);
 
-        // ---- fused top-k epilogue of tile te (this tile for waves 0-3, the previous one for 4-7).
-        // acc[j] is (corpus row base + (j&3) + 8*(j>>2) + 4h, query r).
-        const int te = late ? t - 1 : t;
-        if (te >= 0 && te < ntiles) {
-            const long tile_row0 = (long)(tile_lo + te) * tile_step_rows;
-            const bool ragged = tile_row0 + TILE_ROWS > n;       // wave-uniform, last tile only
+            // ---- fused top-k epilogue of sub-step ge (this one for waves 0-3, the previous one
+            // for 4-7).  acc[j] is (corpus row base + (j&3) + 8*(j>>2) + 4h, query r).
+            const int ge = late ? gs - 1 : gs;
+#ifdef SSS_EXP_NO_EPILOGUE
+            if (ge >= 0 && ge < nsub) { asm volatile("" :: "v"(acc0), "v"(acc1)); }
+            if (false) {
+#else
+            if (ge >= 0 && ge < nsub) {
+#endif
+                const long sub_row0 = (long)(tile_lo + ge / H) * tile_step_rows + (ge % H) * 64;
+                const bool ragged = sub_row0 + 64 > n;          // wave-uniform, last tile only
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                f32x16 a = mb ? acc1 : acc0;
-                const int base = (int)tile_row0 + mb * 32 + 4 * h;
-                if (ragged) {
+                for (int mb = 0; mb < 2; ++mb) {
+                    f32x16 a = mb ? acc1 : acc0;
+                    const int base = (int)sub_row0 + mb * 32 + 4 * h;
+                    if (ragged) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (base + (j & 3) + 8 * (j >> 2) >= n) a[j] = -INFINITY;
-                }
-                float m = fmaxf(fmaxf(a[0], a[1]), a[2]);
+                        for (int j = 0; j < 16; ++j)
+                            if (base + (j & 3) + 8 * (j >> 2) >= n) a[j] = -INFINITY;
+                    }
+                    float m = fmaxf(fmaxf(a[0], a[1]), a[2]);
 #pragma unroll
-                for (int j = 3; j < 15; j += 2) m = fmaxf(fmaxf(m, a[j]), a[j + 1]);
-                m = fmaxf(m, a[15]);
-                if (PRE) { pend_s = fmaxf(pend_s, m); continue; }
-                if (__builtin_amdgcn_ballot_w64(m > ls[KP - 1]) != 0) {
-                    // A passing score parks in the lane's one pending slot; the 80-instruction
-                    // sorted insert runs only when some lane needs its slot again (then every
-                    // lane's pending entry goes in with that same pass).  ls[KP-1] may therefore
-                    // lag behind -- it only admits extra candidates, never drops one.
+                    for (int j = 3; j < 15; j += 2) m = fmaxf(fmaxf(m, a[j]), a[j + 1]);
+                    m = fmaxf(m, a[15]);
+                    if (PRE) { pend_s = fmaxf(pend_s, m); continue; }
+                    if (__builtin_amdgcn_ballot_w64(m > ls[KP - 1]) != 0) {
+                        // A passing score parks in the lane's one pending slot; the 80-instruction
+                        // sorted insert runs only when some lane needs its slot again (then every
+                        // lane's pending entry goes in with that same pass).  ls[KP-1] may
+                        // therefore lag behind -- it only admits extra candidates, never drops one.
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const bool pass = a[j] > ls[KP - 1];
-                        if (__builtin_amdgcn_ballot_w64(pass) != 0) {
-                            if (__builtin_amdgcn_ballot_w64(pass && pend_i >= 0) != 0) {
-                                list_insert<KP>(ls, li, pend_s, pend_i);
-                                pend_s = -INFINITY; pend_i = -1;
+                        for (int j = 0; j < 16; ++j) {
+                            const bool pass = a[j] > ls[KP - 1];
+                            if (__builtin_amdgcn_ballot_w64(pass) != 0) {
+                                if (__builtin_amdgcn_ballot_w64(pass && pend_i >= 0) != 0) {
+                                    list_insert<KP>(ls, li, pend_s, pend_i);
+                                    pend_s = -INFINITY; pend_i = -1;
+                                }
+                                const bool still = a[j] > ls[KP - 1];
+                                pend_s = still ? a[j] : pend_s;
+                                pend_i = still ? base + (j & 3) + 8 * (j >> 2) : pend_i;
                             }
-                            const bool still = a[j] > ls[KP - 1];
-                            pend_s = still ? a[j] : pend_s;
-                            pend_i = still ? base + (j & 3) + 8 * (j >> 2) : pend_i;
                         }
                     }
                 }
             }
+            if (late && t < ntiles) mfma_sub(buf, sub, next_tile);
         }
-        if (late && t < ntiles) mfma_tile(buf, next_tile);
+#ifndef SSS_EXP_NO_STAGE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile landed
+#endif
+#if !defined(SSS_EXP_NO_STAGE) || defined(SSS_EXP_KEEP_BARRIER)
+#ifndef SSS_EXP_NO_BARRIER
         __syncthreads();                                   // ... everyone's did, and this buffer is free
+#endif
+#endif
     }
 
     if (PRE) {      // lane maximum -> cand_s[q][split*2 + h]
@@ -508,24 +553,28 @@ int profile_read(double* total_ms, int* launches) {
     return SSS_OK;
 }
 
-static int pick_splits(long n, int G) {
-    // S*G workgroups, one per CU (256 CUs); S a multiple of 8 (XCD remap); >= 64 rows a split.
+static int tile_rows_for(int d) { return d <= 128 ? 128 : 64; }   // == ScanCfg<D>::TR
+
+static int pick_splits(long n, int G, int tr) {
+    // S*G workgroups, one per CU (256 CUs); S a multiple of 8 (XCD remap); >= one tile a split.
     int S = (256 / G) & ~7;
     if (S < 8) S = 8;
-    while (S > 8 && (long)S * TILE_ROWS > n) S -= 8;
+    while (S > 8 && (long)S * tr > n) S -= 8;
     return S;
 }
 
 struct ScanPlan {
-    int G, S, L, K2;
+    int G, S, L, K2, tile_rows;
     int total_tiles, tiles_per_split;       // main pass
     int pre_tiles, pre_tiles_per_split, pre_step_rows;   // sampled pre-pass (pre_tiles == 0: none)
 };
 
-static ScanPlan make_plan(long nq, long n, int k) {
+static ScanPlan make_plan(long nq, long n, int d, int k) {
     ScanPlan p;
+    const int TILE_ROWS = tile_rows_for(d);
+    p.tile_rows = TILE_ROWS;
     p.G = (int)((nq + WG_QUERIES - 1) / WG_QUERIES);
-    p.S = pick_splits(n, p.G);
+    p.S = pick_splits(n, p.G, TILE_ROWS);
     p.L = 2 * p.S;
     p.K2 = k + (k <= 12 ? KP - k : 12);
     if (p.L * KP < p.K2) p.K2 = p.L * KP;
@@ -534,7 +583,7 @@ static ScanPlan make_plan(long nq, long n, int k) {
     // Pre-pass sample: about 2n/L rows (so a lane list of the main pass admits ~KP rows),
     // at least 4 tiles a split, evenly spaced tiles; skipped unless it is < 1/8 of the corpus.
     long want_rows = 2 * n / p.L;
-    if (want_rows < 4L * TILE_ROWS * p.S) want_rows = 4L * TILE_ROWS * p.S;
+    if (want_rows < 256L * p.S) want_rows = 256L * p.S;
     int ptps = (int)((want_rows / TILE_ROWS + p.S - 1) / p.S);
     p.pre_tiles = 0; p.pre_tiles_per_split = 0; p.pre_step_rows = 0;
     if ((long)ptps * p.S * 8 <= p.total_tiles && p.L >= p.K2 && p.L <= 512) {
@@ -546,13 +595,13 @@ static ScanPlan make_plan(long nq, long n, int k) {
 }
 
 size_t ip_topk_workspace_bytes(long nq, long n, int d, int k) {
-    const ScanPlan p = make_plan(nq, n, k);
+    const ScanPlan p = make_plan(nq, n, d, k);
     return (size_t)nq * p.L * KP * 8 + (size_t)nq * 4 + 256;
 }
 
 template <int D>
 static void set_lds_attr() {
-    const int lds = 2 * TILE_ROWS * D * 4;
+    const int lds = 2 * ScanCfg<D>::TR * D * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_topk_f32<D, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ip_topk_f32<D, true>),
@@ -562,7 +611,7 @@ static void set_lds_attr() {
 template <int D>
 static int launch_scan(const float* q, int nq, const float* c, int n, const ScanPlan& p, bool pre,
                        const float* tau, float* cs, int* ci, hipStream_t st) {
-    const size_t lds = 2 * TILE_ROWS * D * 4;
+    const size_t lds = 2 * ScanCfg<D>::TR * D * 4;
     static bool attr_done = false;
     if (!attr_done) { set_lds_attr<D>(); attr_done = true; }
     if (pre)
@@ -571,7 +620,7 @@ static int launch_scan(const float* q, int nq, const float* c, int n, const Scan
                            (const float*)nullptr, cs, ci);
     else
         hipLaunchKernelGGL((k_ip_topk_f32<D, false>), dim3(p.S * p.G), dim3(512), lds, st, q, nq, c, n,
-                           p.tiles_per_split, p.total_tiles, TILE_ROWS, p.S, p.G, tau, cs, ci);
+                           p.tiles_per_split, p.total_tiles, p.tile_rows, p.S, p.G, tau, cs, ci);
     return check_launch("k_ip_topk_f32");
 }
 
@@ -587,9 +636,9 @@ int ip_topk_f32(const float* q, long nq, const float* c, long n, int d, int k, l
                 size_t ws_bytes, hipStream_t st) {
     if (nq <= 0 || n <= 0 || k <= 0) { set_error("ip_topk: nq, n, k must be positive"); return SSS_EINVAL; }
     if (d != 64 && d != 128 && d != 256) { set_error("ip_topk: d must be 64, 128 or 256 (got %d)", d); return SSS_EINVAL; }
-    if (n >= (1L << 31) - 2 * TILE_ROWS || nq >= (1L << 31)) { set_error("ip_topk: n and nq must be < 2^31 per shard"); return SSS_EINVAL; }
+    if (n >= (1L << 31) - 1024 || nq >= (1L << 31)) { set_error("ip_topk: n and nq must be < 2^31 per shard"); return SSS_EINVAL; }
     if (k + 12 > SEL_MAX_K2) { set_error("ip_topk: k too large (max %d)", SEL_MAX_K2 - 12); return SSS_EINVAL; }
-    const ScanPlan p = make_plan(nq, n, k);
+    const ScanPlan p = make_plan(nq, n, d, k);
     const size_t need = ip_topk_workspace_bytes(nq, n, d, k);
     if (ws_bytes < need) { set_error("ip_topk: workspace %zu < %zu", ws_bytes, need); return SSS_EWORKSPACE; }
     float* cs = reinterpret_cast<float*>(ws);
