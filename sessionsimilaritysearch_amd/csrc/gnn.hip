@@ -24,59 +24,60 @@ namespace sss {
 // per-workgroup latency, not FLOPs, bounds them, so the K loop is 1-3 steps and two workgroups
 // share a CU (64 KiB LDS each).
 constexpr int LT = 64;      // tile rows (X) and columns (W rows)
-constexpr int LKC = 128;    // K chunk
 
+template <int KC>           // K chunk: 128, 64 or 32 (K % KC == 0)
 __global__ __launch_bounds__(256, 2) void k_linear_f32(const float* __restrict__ X, long ldx,
                                                        const float* __restrict__ W, long ldw,
                                                        const float* __restrict__ bias, float* __restrict__ Y,
                                                        long ldy, long N, int M, int K) {
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];        // [X|W][64 rows][128]
+    constexpr int CPR = KC / 4;                 // 16-byte chunks per staged row
+    constexpr int NLD = LT * CPR / 256;         // float4 loads per thread per operand (8, 4, 2)
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];        // [X|W][64 rows][32 chunks]
     float* lx = lds_raw;
-    float* lw = lds_raw + LT * LKC;
+    float* lw = lds_raw + LT * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const long row0 = (long)blockIdx.x * LT;
     const int col0 = blockIdx.y * LT;
+    const int xr = wr * 32 + r, wrow = wc * 32 + r;
 
     f32x16 acc = {0};
-    for (int k0 = 0; k0 < K; k0 += LKC) {
-        const int kc = K - k0 < LKC ? K - k0 : LKC;        // multiple of 32
-        const int cpr = kc / 4;                              // 16-byte chunks per row (8..32)
-        const int total = LT * cpr;
-        float4 sx[8], sw[8];
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        f32x4 sx[NLD], sw[NLD];          // ext-vector type: stays in VGPRs (HIP's float4 struct array went to scratch)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             const int p = tid + 256 * i;
-            if (p < total) {
-                const int tr = p / cpr, c = p % cpr;
-                long gr = row0 + tr; if (gr > N - 1) gr = N - 1;
-                int gw = col0 + tr; if (gw > M - 1) gw = M - 1;
-                sx[i] = *reinterpret_cast<const float4*>(X + gr * ldx + k0 + c * 4);
-                sw[i] = *reinterpret_cast<const float4*>(W + (long)gw * ldw + k0 + c * 4);
-            }
+            const int tr = p / CPR, c = p % CPR;
+            long gr = row0 + tr; if (gr > N - 1) gr = N - 1;
+            int gw = col0 + tr; if (gw > M - 1) gw = M - 1;
+            sx[i] = *reinterpret_cast<const f32x4*>(X + gr * ldx + k0 + c * 4);
+            sw[i] = *reinterpret_cast<const f32x4*>(W + (long)gw * ldw + k0 + c * 4);
         }
         if (k0 > 0) __syncthreads();                         // previous chunk fully consumed
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             const int p = tid + 256 * i;
-            if (p < total) {
-                const int tr = p / cpr, c = p % cpr;
-                const int cs = c ^ (tr & 15);                // rows are 32 chunks apart: stays in the row
-                *reinterpret_cast<float4*>(lx + (tr * 32 + cs) * 4) = sx[i];
-                *reinterpret_cast<float4*>(lw + (tr * 32 + cs) * 4) = sw[i];
-            }
+            const int tr = p / CPR, c = p % CPR;
+            const int cs = c ^ (tr & 15);                    // rows are 32 chunks apart: stays in the row
+            *reinterpret_cast<f32x4*>(lx + (tr * 32 + cs) * 4) = sx[i];
+            *reinterpret_cast<f32x4*>(lw + (tr * 32 + cs) * 4) = sw[i];
         }
         __syncthreads();
-        const int xr = wr * 32 + r, wrow = wc * 32 + r;
-        const int nu = kc / 8;
-        for (int u = 0; u < nu; ++u) {
-            const float4 a = *reinterpret_cast<const float4*>(lx + (xr * 32 + ((2 * u + h) ^ (xr & 15))) * 4);
-            const float4 b = *reinterpret_cast<const float4*>(lw + (wrow * 32 + ((2 * u + h) ^ (wrow & 15))) * 4);
+        float4 a = *reinterpret_cast<const float4*>(lx + (xr * 32 + (h ^ (xr & 15))) * 4);
+        float4 b = *reinterpret_cast<const float4*>(lw + (wrow * 32 + (h ^ (wrow & 15))) * 4);
+#pragma unroll
+        for (int u = 0; u < KC / 8; ++u) {
+            float4 na = a, nb = b;
+            if (u + 1 < KC / 8) {                            // fragments one k-group ahead
+                na = *reinterpret_cast<const float4*>(lx + (xr * 32 + ((2 * u + 2 + h) ^ (xr & 15))) * 4);
+                nb = *reinterpret_cast<const float4*>(lw + (wrow * 32 + ((2 * u + 2 + h) ^ (wrow & 15))) * 4);
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            a = na; b = nb;
         }
     }
     // C/D map of 32x32: col = lane & 31 (W row), row = (j & 3) + 8 * (j >> 2) + 4 * h (X row)
@@ -339,14 +340,20 @@ int linear_f32(const float* X, long ldx, const float* W, long ldw, const float* 
     }
     if (N == 0) return SSS_OK;
     dim3 grid((unsigned)((N + LT - 1) / LT), (unsigned)((M + LT - 1) / LT));
-    const int lds = 2 * LT * LKC * 4;
+    const int lds = 2 * LT * 128 * 4;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_f32),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_f32<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_f32<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_linear_f32, grid, dim3(256), lds, st, X, ldx, W, ldw, bias, Y, ldy, N, M, K);
+    if (K % 128 == 0)
+        hipLaunchKernelGGL(k_linear_f32<128>, grid, dim3(256), lds, st, X, ldx, W, ldw, bias, Y, ldy, N, M, K);
+    else if (K % 64 == 0)
+        hipLaunchKernelGGL(k_linear_f32<64>, grid, dim3(256), lds, st, X, ldx, W, ldw, bias, Y, ldy, N, M, K);
+    else
+        hipLaunchKernelGGL(k_linear_f32<32>, grid, dim3(256), lds, st, X, ldx, W, ldw, bias, Y, ldy, N, M, K);
     return check_launch("k_linear_f32");
 }
 
