@@ -71,10 +71,9 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    // Waves 4-7 are the SIMD partners of waves 0-3.  They run their top-k epilogue one sub-step
-    // LATE (the last one of a tile after the barrier, under the partner's first MFMAs of the
-    // next tile) so the two waves of a SIMD are never both outside their MFMA stream.
-    const bool late = wave >= 4;                    // wave-uniform (scalar branch)
+    // (Deferring the epilogue of waves 4-7 by one sub-step -- the "stagger" of the MI355X guide --
+    // was measured here at 1M and 10M rows: no gain over running every wave in phase, so the
+    // simpler in-phase form is kept.)
 
     // XCD-aware remap: blocks b and b+8 share an XCD (and its L2); the G query groups that
     // stream the same corpus split are given consecutive slots of ONE XCD so the split is
@@ -201,66 +200,71 @@ __global__ __launch_bounds__(512, 2) void k_ip_topk_f32(
         }
     };
 
+    // Top-k epilogue of one 32x32 accumulator: a[j] is (corpus row base + (j&3) + 8*(j>>2), query r).
+    // Hot path: quarter maxima (rows 8g..8g+3 of this lane's 16) + one compare.  When some lane's
+    // maximum beats its list tail, only the quarters that hold a passing score are walked.
+    auto epilogue_block = [&](const f32x16& a, int base) {
+        const float q0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+        const float q1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
+        const float q2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
+        const float q3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
+        const float m = fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
+        if (PRE) { pend_s = fmaxf(pend_s, m); return; }
+        if (__builtin_amdgcn_ballot_w64(m > ls[KP - 1]) == 0) return;
+        // A passing score parks in the lane's one pending slot; the 80-instruction sorted insert
+        // runs only when some lane needs its slot again (then every lane's pending entry goes in
+        // with that same pass).  ls[KP-1] may therefore lag behind -- it only admits extra
+        // candidates, never drops one.
+        auto walk = [&](float qm, int j0) {
+            if (__builtin_amdgcn_ballot_w64(qm > ls[KP - 1]) == 0) return;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = j0 + jj;
+                const bool pass = a[j] > ls[KP - 1];
+                if (__builtin_amdgcn_ballot_w64(pass) != 0) {
+                    if (__builtin_amdgcn_ballot_w64(pass && pend_i >= 0) != 0) {
+                        list_insert<KP>(ls, li, pend_s, pend_i);
+                        pend_s = -INFINITY; pend_i = -1;
+                    }
+                    const bool still = a[j] > ls[KP - 1];
+                    pend_s = still ? a[j] : pend_s;
+                    pend_i = still ? base + (j & 3) + 8 * (j >> 2) : pend_i;
+                }
+            }
+        };
+        walk(q0, 0); walk(q1, 4); walk(q2, 8); walk(q3, 12);     // ascending row order per lane
+    };
+
     if (ntiles > 0) stage(0, tile_lo);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ntiles + 1 iterations: the last one only drains the late waves' deferred epilogue.
-    const int nsub = ntiles * H;
-    for (int t = 0; t <= ntiles; ++t) {
+    for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         for (int sub = 0; sub < H; ++sub) {
-            const int gs = t * H + sub;                        // global sub-step index
             const int next_tile = (sub == 0 && t + 1 < ntiles) ? tile_lo + t + 1 : -1;
-            if (!late && t < ntiles) mfma_sub(buf, sub, next_tile);
+            mfma_sub(buf, sub, next_tile);
 
-            // ---- fused top-k epilogue of sub-step ge (this one for waves 0-3, the previous one
-            // for 4-7).  acc[j] is (corpus row base + (j&3) + 8*(j>>2) + 4h, query r).
-            const int ge = late ? gs - 1 : gs;
+            // ---- fused top-k epilogue of this sub-step.
+            // acc[j] is (corpus row base + (j&3) + 8*(j>>2) + 4h, query r).
 #ifdef SSS_EXP_NO_EPILOGUE
-            if (ge >= 0 && ge < nsub) { asm volatile("" :: "v"(acc0), "v"(acc1)); }
+            asm volatile("" :: "v"(acc0), "v"(acc1));
             if (false) {
 #else
-            if (ge >= 0 && ge < nsub) {
+            {
 #endif
-                const long sub_row0 = (long)(tile_lo + ge / H) * tile_step_rows + (ge % H) * 64;
-                const bool ragged = sub_row0 + 64 > n;          // wave-uniform, last tile only
+                const long sub_row0 = (long)(tile_lo + t) * tile_step_rows + sub * 64;
+                if (sub_row0 + 64 > n) {                        // wave-uniform, last tile only
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) {
-                    f32x16 a = mb ? acc1 : acc0;
-                    const int base = (int)sub_row0 + mb * 32 + 4 * h;
-                    if (ragged) {
-#pragma unroll
-                        for (int j = 0; j < 16; ++j)
-                            if (base + (j & 3) + 8 * (j >> 2) >= n) a[j] = -INFINITY;
-                    }
-                    float m = fmaxf(fmaxf(a[0], a[1]), a[2]);
-#pragma unroll
-                    for (int j = 3; j < 15; j += 2) m = fmaxf(fmaxf(m, a[j]), a[j + 1]);
-                    m = fmaxf(m, a[15]);
-                    if (PRE) { pend_s = fmaxf(pend_s, m); continue; }
-                    if (__builtin_amdgcn_ballot_w64(m > ls[KP - 1]) != 0) {
-                        // A passing score parks in the lane's one pending slot; the 80-instruction
-                        // sorted insert runs only when some lane needs its slot again (then every
-                        // lane's pending entry goes in with that same pass).  ls[KP-1] may
-                        // therefore lag behind -- it only admits extra candidates, never drops one.
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) {
-                            const bool pass = a[j] > ls[KP - 1];
-                            if (__builtin_amdgcn_ballot_w64(pass) != 0) {
-                                if (__builtin_amdgcn_ballot_w64(pass && pend_i >= 0) != 0) {
-                                    list_insert<KP>(ls, li, pend_s, pend_i);
-                                    pend_s = -INFINITY; pend_i = -1;
-                                }
-                                const bool still = a[j] > ls[KP - 1];
-                                pend_s = still ? a[j] : pend_s;
-                                pend_i = still ? base + (j & 3) + 8 * (j >> 2) : pend_i;
-                            }
-                        }
+                    for (int j = 0; j < 16; ++j) {
+                        const int rr = (int)sub_row0 + 4 * h + (j & 3) + 8 * (j >> 2);
+                        if (rr >= n) acc0[j] = -INFINITY;
+                        if (rr + 32 >= n) acc1[j] = -INFINITY;
                     }
                 }
+                epilogue_block(acc0, (int)sub_row0 + 4 * h);
+                epilogue_block(acc1, (int)sub_row0 + 32 + 4 * h);
             }
-            if (late && t < ntiles) mfma_sub(buf, sub, next_tile);
         }
 #ifndef SSS_EXP_NO_STAGE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile landed
