@@ -193,18 +193,34 @@ def build_index(emb, metric):
 
 # -------------------------------------------------------------------- neighbour vote, p / r
 def knn_item_vote(D_row, I_row, session_items, K):
-    """``get_prediction_by_knn`` after the search (test_amazon_filterd.py:64-78): every item
-    of neighbour session i gets weight D[i]; weights are summed per item in float32 in
-    neighbour order, and the K heaviest items are returned (python's stable sort: ties keep
+    """``get_prediction_by_knn`` after the search (test_amazon_filterd.py:64-78).  Every item of
+    neighbour session i gets weight D[i]: the reference multiplies an int64 ``ones_like`` array by
+    the float32 scalar ``D[i]`` (-> a float64 array, :69) and adds those float64 values to a
+    Python accumulator that starts at int 0 (:71-73), so weights are summed IN FLOAT64, in
+    neighbour order; the K heaviest items are returned (python's stable sort, :74: ties keep
     first-seen order)."""
-    aw = defaultdict(lambda: np.float32(0))
+    aw = defaultdict(lambda: 0)
     for dist, sid in zip(D_row, I_row):
         if sid < 0:
             continue
+        wgt = np.float64(np.float32(dist))
         for item in session_items[int(sid)]:
-            aw[int(item)] = np.float32(aw[int(item)] + np.float32(dist))
+            aw[int(item)] += wgt
     sorted_aw = sorted(aw.items(), key=lambda x: x[1], reverse=True)
     return [p[0] for p in sorted_aw[:K]]
+
+
+def knn_item_vote_weights(D_row, I_row, session_items, K):
+    """Same vote, also returning the float64 weights of the K items (checker for the device kernel)."""
+    aw = defaultdict(lambda: 0)
+    for dist, sid in zip(D_row, I_row):
+        if sid < 0:
+            continue
+        wgt = np.float64(np.float32(dist))
+        for item in session_items[int(sid)]:
+            aw[int(item)] += wgt
+    sorted_aw = sorted(aw.items(), key=lambda x: x[1], reverse=True)[:K]
+    return [p[0] for p in sorted_aw], [float(p[1]) for p in sorted_aw]
 
 
 def get_p_r(gt, pred, K):

@@ -25,8 +25,10 @@ def run(nq, n, d, k, iters=5):
                           qps=round(nq / (ms * 1e-3)), unproven=bad)), flush=True)
 
 if __name__ == "__main__":
-    shapes = [(1024, 100_000, 128, 10), (1024, 1_000_000, 128, 10), (1024, 10_000_000, 128, 10),
+    shapes = [(1024, 125_000, 128, 10), (1024, 250_000, 128, 10), (1024, 500_000, 128, 10),
+              (1024, 1_000_000, 128, 10), (1024, 10_000_000, 128, 10),
               (256, 1_000_000, 128, 10), (4096, 1_000_000, 128, 10), (1024, 1_000_000, 64, 10),
-              (1024, 1_000_000, 256, 10), (1024, 1_000_000, 128, 100)]
+              (1024, 1_000_000, 256, 10), (1024, 1_000_000, 128, 100), (1024, 125_000, 64, 10),
+              (1024, 125_000, 128, 100)]
     for s in shapes:
         run(*s)

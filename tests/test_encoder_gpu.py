@@ -209,3 +209,40 @@ def test_end_to_end_retrieval_matches_oracle_pipeline(cuda):
     Dro, Iro = sr.build_index(ref, "cos").search(sr.normalize(ref), 10)
     assert sr.recall_at_k(I, Iro, 10) >= 0.999
     assert np.abs(D - Dro).max() < 1e-5
+
+
+# ---------------------------------------------------------------------------------- golden fixtures
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_gather_rows_matches_reference_node_asin_embedding(cuda):
+    """tests/golden/node_asin_embedding.npz was produced by the reference's own NodeAsinEmbedding
+    (model/NodeEmbedding.py:128-138, script tests/golden/make_golden.py): the HIP gather must
+    reproduce it bit for bit, also into a strided node buffer."""
+    z = np.load(os.path.join(GOLDEN, "node_asin_embedding.npz"), allow_pickle=False)
+    table, ids = torch.from_numpy(z["table"]).to(cuda), torch.from_numpy(z["ids"]).to(cuda)
+    n, d = ids.shape[0], table.shape[1]
+    for ld in (d, d + 12):
+        out = torch.full((n, ld), -7.0, device=cuda)
+        rc = _lib.lib().sss_gather_rows(table.data_ptr(), ids.data_ptr(), n, d, out.data_ptr(), ld, _st(cuda))
+        _lib.check(rc, "gather")
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:, :d], z["out"]) and (got[:, d:] == -7.0).all()
+
+
+@pytest.mark.parametrize("loops,tag", [(True, "loops"), (False, "noloops")])
+def test_encoder_matches_independent_float64_fixture(cuda, loops, tag):
+    """HIP encoder vs tests/golden/encoder_tiny.npz (independent numpy-float64 oracle)."""
+    z = np.load(os.path.join(GOLDEN, "encoder_tiny.npz"), allow_pickle=False)
+    acts = S.ActionTable(z["sess_ptr"], z["is_search"], z["item_id"], z["query_tok"])
+    w = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    d_in, h, L, d_out, n_items, n_query = (int(v) for v in z["cfg"])
+    cfg = EncoderConfig(d_in=d_in, h=h, n_layers=L, d_out=d_out, n_items=n_items, n_query=n_query,
+                        self_loop_rule="pyg_bipartite_global" if loops else "none")
+    enc = SessionEncoder(cfg, w, cuda)
+    out, nodes = enc(S.build_batch(acts).to(cuda), get_node=True)
+    assert np.abs(out.cpu().numpy() - z["out_" + tag]).max() < TOL
+    assert np.abs(nodes["query"].cpu().numpy() - z["node_q_" + tag]).max() < TOL
+    assert np.abs(nodes["product"].cpu().numpy() - z["node_p_" + tag]).max() < TOL

