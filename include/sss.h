@@ -37,30 +37,39 @@ const char* sss_last_error(void);
  * (one float, atomically maximised; caller zeroes it) -- used by the index for its error bound. */
 int sss_normalize_rows(float* x, int64_t n, int d, int64_t ld, float eps, int rule, void* stream);
 
-/* max over rows of ||x_i||_2 -> *out (device float, caller zeroes). */
-int sss_row_norm_max(const float* x, int64_t n, int d, float* out, void* stream);
+/* max over rows of ||x_i||_2 -> *out (device float, caller zeroes).  dtype 0: x is float32
+ * (d % 4 == 0); dtype 1: x is bfloat16 (d % 8 == 0). */
+int sss_row_norm_max(const void* x, int64_t n, int d, int dtype, float* out, void* stream);
+
+/* float32 -> bfloat16 (round to nearest even) of `count` contiguous elements (count % 8 == 0):
+ * how a corpus / query block enters the bf16 index (BASELINE config C5). */
+int sss_f32_to_bf16(const float* x, int64_t count, uint16_t* y, void* stream);
 
 /* ---- (ii) IndexFlatIP.search -- test_amazon_filterd.py:578 (also :61,661; fine_tune_ours.py:882).
- * q [nq, d] fp32, corpus [n, d] fp32 (row-major, as IndexFlatIP.add stored it), d in {64,128,256},
- * k <= 116.  Writes D_out [nq, k] fp32 (descending) and I_out [nq, k] int64 = row + id_offset,
+ * dtype 0: q [nq, d] and corpus [n, d] float32 (row-major, as IndexFlatIP.add stored it), d in
+ * {64,128,256}; dtype 1: both bfloat16, d in {128,256,512} (f32 accumulate on the bf16 MFMA).
+ * k <= 500.  Writes D_out [nq, k] fp32 (descending) and I_out [nq, k] int64 = row + id_offset,
  * ordered by (score desc, id asc); missing results: I = -1, D = -FLT_MAX (faiss convention).
- * Scores are the canonical ones of DESIGN.md (float64 sequential dot rounded to float32).
- * status [nq] int32: 0 = proven exact, 1 = not proven (caller re-runs those queries through
- * sss_ip_topk_exhaustive).  corpus_max_norm = max row 2-norm of the corpus (for the bound).
- * metric: 0 = inner product, 1 = squared L2 (IndexFlatL2, test_amazon_filterd.py:215-217;
- * D ascending). */
-size_t sss_ip_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k);
-int sss_ip_topk(const float* q, int64_t nq, const float* corpus, int64_t n, int d, int k,
+ * Scores are the canonical ones of DESIGN.md (float64 sequential dot of the stored elements,
+ * rounded to float32).  status [nq] int32: 0 = proven exact, 1 = not proven (caller re-runs those
+ * queries through sss_ip_topk_exhaustive).  corpus_max_norm = max row 2-norm of the corpus (for
+ * the error bound).  workspace: 256-byte aligned, sss_ip_topk_workspace_bytes() bytes (0 = shape
+ * not supported by the fused path). */
+size_t sss_ip_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k, int dtype);
+int sss_ip_topk(const void* q, int64_t nq, const void* corpus, int64_t n, int d, int k, int dtype,
                 int64_t id_offset, float corpus_max_norm, float* D_out, int64_t* I_out,
                 int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Exhaustive exact search for a (small) set of queries: qsel [nsel] int32 are the query rows of
- * q to process; results are written to rows qsel[i] of D_out / I_out.  Any n, any d % 4 == 0,
- * k <= 1024.  workspace: sss_ip_topk_exhaustive_workspace_bytes(nsel, n). */
+ * q to process; results are written to rows qsel[i] of D_out / I_out.  Any n, any d % 4 == 0
+ * (dtype 0) or d % 8 == 0 (dtype 1), k <= 1024.  metric: 0 = inner product, 1 = squared L2
+ * (IndexFlatL2, test_amazon_filterd.py:215-217; D ascending).
+ * workspace: sss_ip_topk_exhaustive_workspace_bytes(nsel, n). */
 size_t sss_ip_topk_exhaustive_workspace_bytes(int64_t nsel, int64_t n);
-int sss_ip_topk_exhaustive(const float* q, const int32_t* qsel, int64_t nsel, const float* corpus,
-                           int64_t n, int d, int k, int64_t id_offset, int metric, float* D_out,
-                           int64_t* I_out, void* workspace, size_t workspace_bytes, void* stream);
+int sss_ip_topk_exhaustive(const void* q, const int32_t* qsel, int64_t nsel, const void* corpus,
+                           int64_t n, int d, int k, int dtype, int64_t id_offset, int metric,
+                           float* D_out, int64_t* I_out, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 /* ---- multi-GPU: merge per-shard results after the all-gather (no reference equivalent; the
  * reference is single process).  Shard s's [nq, k] block starts at D_in + s * d_shard_stride
@@ -71,7 +80,8 @@ int sss_topk_merge(const float* D_in, int64_t d_shard_stride, const int64_t* I_i
 /* ---- measurement aid (bench.py roofline leg): when enabled, every launch of the dominant
  * scoring kernel inside sss_ip_topk is bracketed by a hipEvent pair on its own stream;
  * sss_profile_read synchronises them and returns the summed duration and the launch count
- * since the last read (process-global, at most 512 launches between reads). */
+ * since the last read (state is per device: the calling thread's current device; at most 512
+ * launches between reads). */
 int sss_profile_enable(int on);
 int sss_profile_read(double* total_ms, int* launches);
 

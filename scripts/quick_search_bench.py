@@ -4,12 +4,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sessionsimilaritysearch_amd.index import FlatIndex, normalize_
 
-def run(nq, n, d, k, iters=5):
+PEAK = {"f32": 157.3, "bf16": 2500.0}      # MI355X_MICROARCH.md dense peaks, TFLOP/s
+
+def run(nq, n, d, k, dtype="f32", iters=5):
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev); g.manual_seed(1)
     c = torch.randn((n, d), device=dev, generator=g); normalize_(c)
     q = torch.randn((nq, d), device=dev, generator=g); normalize_(q)
-    idx = FlatIndex(d, "ip", dev).adopt(c)
+    if dtype == "bf16":
+        from sessionsimilaritysearch_amd.index import to_bf16
+        c, q = to_bf16(c), to_bf16(q)
+    idx = FlatIndex(d, "ip", dev, dtype=dtype).adopt(c)
     idx.corpus_max_norm()
     out = idx.search_fused(q, k)
     torch.cuda.synchronize()
@@ -21,7 +26,7 @@ def run(nq, n, d, k, iters=5):
     ms = e0.elapsed_time(e1) / iters
     tf = 2.0 * nq * n * d / (ms * 1e-3) / 1e12
     bad = int(out[2].sum().item())
-    print(json.dumps(dict(nq=nq, n=n, d=d, k=k, ms=round(ms, 4), tflops=round(tf, 2), frac=round(tf / 157.3, 4),
+    print(json.dumps(dict(nq=nq, n=n, d=d, k=k, dtype=dtype, ms=round(ms, 4), tflops=round(tf, 2), frac=round(tf / PEAK[dtype], 4),
                           qps=round(nq / (ms * 1e-3)), unproven=bad)), flush=True)
 
 if __name__ == "__main__":
@@ -29,6 +34,9 @@ if __name__ == "__main__":
               (1024, 1_000_000, 128, 10), (1024, 10_000_000, 128, 10),
               (256, 1_000_000, 128, 10), (4096, 1_000_000, 128, 10), (1024, 1_000_000, 64, 10),
               (1024, 1_000_000, 256, 10), (1024, 1_000_000, 128, 100), (1024, 125_000, 64, 10),
-              (1024, 125_000, 128, 100)]
+              (1024, 125_000, 128, 100), (1024, 4_000_000, 128, 500),
+              (4096, 1_250_000, 256, 10, "bf16"), (4096, 10_000_000, 256, 10, "bf16"), (1024, 1_000_000, 256, 10, "bf16")]
+    if len(sys.argv) > 1:
+        shapes = [tuple(int(v) if v.isdigit() else v for v in a.split(",")) for a in sys.argv[1:]]
     for s in shapes:
         run(*s)

@@ -11,7 +11,7 @@ import subprocess
 from ctypes import c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SSS_LIB_PATH") or os.path.join(_HERE, "libsss.so")   # env override: dev ablation builds
+LIB_PATH = os.path.join(_HERE, "libsss.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None
@@ -21,12 +21,13 @@ _SIGNATURES = {
     "sss_version": (c_int, []),
     "sss_last_error": (ctypes.c_char_p, []),
     "sss_normalize_rows": (c_int, [c_void_p, c_int64, c_int, c_int64, c_float, c_int, c_void_p]),
-    "sss_row_norm_max": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
-    "sss_ip_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
-    "sss_ip_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_float,
+    "sss_row_norm_max": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "sss_f32_to_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "sss_ip_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
+    "sss_ip_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_float,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sss_ip_topk_exhaustive_workspace_bytes": (c_size_t, [c_int64, c_int64]),
-    "sss_ip_topk_exhaustive": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
+    "sss_ip_topk_exhaustive": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                        c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                        c_void_p]),
     "sss_topk_merge": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_void_p,

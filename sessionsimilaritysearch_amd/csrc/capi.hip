@@ -26,17 +26,18 @@ int check_launch(const char* what) {
 }
 
 // implemented in the kernel translation units
-size_t ip_topk_workspace_bytes(long nq, long n, int d, int k);
-int ip_topk_f32(const float*, long, const float*, long, int, int, long, float, float*, long*, int*, void*,
-                size_t, hipStream_t);
+size_t ip_topk_workspace_bytes(long nq, long n, int d, int k, int dtype);
+int ip_topk(const void*, long, const void*, long, int, int, int, long, float, float*, long*, int*, void*,
+            size_t, hipStream_t);
 int topk_merge(const float*, long, const long*, long, int, long, int, float*, long*, hipStream_t);
 int profile_enable(int);
 int profile_read(double*, int*);
 size_t ip_topk_exhaustive_workspace_bytes(long nsel, long n);
-int ip_topk_exhaustive(const float*, const int*, long, const float*, long, int, int, long, int, float*, long*,
+int ip_topk_exhaustive(const void*, const int*, long, const void*, long, int, int, int, long, int, float*, long*,
                        void*, size_t, hipStream_t);
 int normalize_rows(float*, long, int, long, float, int, hipStream_t);
-int row_norm_max(const float*, long, int, float*, hipStream_t);
+int row_norm_max(const void*, long, int, int, float*, hipStream_t);
+int f32_to_bf16(const float*, long, unsigned short*, hipStream_t);
 int gather_rows(const float*, const long*, long, int, float*, long, hipStream_t);
 int linear_f32(const float*, long, const float*, long, const float*, float*, long, long, int, int, hipStream_t);
 int gat_aggregate(const float*, long, const float*, long, const float*, long, const int*, const int*, long, int,
@@ -56,31 +57,34 @@ int segment_ptr(const long*, long, long, int*, hipStream_t);
 
 extern "C" {
 
-int sss_version(void) { return 100; }
+int sss_version(void) { return 200; }
 const char* sss_last_error(void) { return sss::g_err; }
 
 int sss_normalize_rows(float* x, int64_t n, int d, int64_t ld, float eps, int rule, void* stream) {
     return sss::normalize_rows(x, n, d, ld, eps, rule, ST(stream));
 }
-int sss_row_norm_max(const float* x, int64_t n, int d, float* out, void* stream) {
-    return sss::row_norm_max(x, n, d, out, ST(stream));
+int sss_row_norm_max(const void* x, int64_t n, int d, int dtype, float* out, void* stream) {
+    return sss::row_norm_max(x, n, d, dtype, out, ST(stream));
 }
-size_t sss_ip_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k) {
-    return sss::ip_topk_workspace_bytes(nq, n, d, k);
+int sss_f32_to_bf16(const float* x, int64_t count, uint16_t* y, void* stream) {
+    return sss::f32_to_bf16(x, count, y, ST(stream));
 }
-int sss_ip_topk(const float* q, int64_t nq, const float* corpus, int64_t n, int d, int k, int64_t id_offset,
+size_t sss_ip_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k, int dtype) {
+    return sss::ip_topk_workspace_bytes(nq, n, d, k, dtype);
+}
+int sss_ip_topk(const void* q, int64_t nq, const void* corpus, int64_t n, int d, int k, int dtype, int64_t id_offset,
                 float corpus_max_norm, float* D_out, int64_t* I_out, int32_t* status, void* workspace,
                 size_t workspace_bytes, void* stream) {
-    return sss::ip_topk_f32(q, nq, corpus, n, d, k, id_offset, corpus_max_norm, D_out,
-                            reinterpret_cast<long*>(I_out), status, workspace, workspace_bytes, ST(stream));
+    return sss::ip_topk(q, nq, corpus, n, d, k, dtype, id_offset, corpus_max_norm, D_out,
+                        reinterpret_cast<long*>(I_out), status, workspace, workspace_bytes, ST(stream));
 }
 size_t sss_ip_topk_exhaustive_workspace_bytes(int64_t nsel, int64_t n) {
     return sss::ip_topk_exhaustive_workspace_bytes(nsel, n);
 }
-int sss_ip_topk_exhaustive(const float* q, const int32_t* qsel, int64_t nsel, const float* corpus, int64_t n,
-                           int d, int k, int64_t id_offset, int metric, float* D_out, int64_t* I_out,
+int sss_ip_topk_exhaustive(const void* q, const int32_t* qsel, int64_t nsel, const void* corpus, int64_t n,
+                           int d, int k, int dtype, int64_t id_offset, int metric, float* D_out, int64_t* I_out,
                            void* workspace, size_t workspace_bytes, void* stream) {
-    return sss::ip_topk_exhaustive(q, qsel, nsel, corpus, n, d, k, id_offset, metric, D_out,
+    return sss::ip_topk_exhaustive(q, qsel, nsel, corpus, n, d, k, dtype, id_offset, metric, D_out,
                                    reinterpret_cast<long*>(I_out), workspace, workspace_bytes, ST(stream));
 }
 int sss_topk_merge(const float* D_in, int64_t d_shard_stride, const int64_t* I_in, int64_t i_shard_stride,

@@ -3,7 +3,7 @@
 // whose fused result could not be proven exact, tiny corpora, k larger than the fused path,
 // the IndexFlatL2 metric of reference test_amazon_filterd.py:215-217, any d % 4 == 0 such as
 // the reference's D = 1600).  It favours simplicity over speed; DESIGN.md "exactness".
-#include "sss_common.h"
+#include "scan.h"
 
 namespace sss {
 
@@ -13,29 +13,39 @@ constexpr int EX_LD = EX_KC + 4;
 
 // scores[f][row] = float32( sum_k q[qsel[f]][k] * c[row][k] ) accumulated sequentially in
 // float64 (metric 0), or sum_k (q_k - c_k)^2 with one rounding per multiply and per add (1).
-__global__ __launch_bounds__(64) void k_exact_scores(const float* __restrict__ Q,
+// DT_BF16: q and c hold bf16; every element converts exactly to float32 on the way into LDS.
+template <int DT>
+__global__ __launch_bounds__(64) void k_exact_scores(const void* __restrict__ Qv,
                                                      const int* __restrict__ qsel,
-                                                     const float* __restrict__ C, long n, int d,
+                                                     const void* __restrict__ Cv, long n, int d,
                                                      int metric, float* __restrict__ scores) {
     __shared__ __attribute__((aligned(16))) float tile[EX_ROWS * EX_LD];
     __shared__ __attribute__((aligned(16))) float qs[EX_KC];
+    constexpr int EB = DT == DT_F32 ? 4 : 2;          // bytes per element
+    constexpr int EPV = 16 / EB;                      // elements per 16-byte load
     const int lane = threadIdx.x;
     const int f = blockIdx.y;
-    const float* q = Q + (size_t)qsel[f] * d;
+    const char* C = reinterpret_cast<const char*>(Cv);
+    const char* q = reinterpret_cast<const char*>(Qv) + (size_t)qsel[f] * d * EB;
+    auto to_f32 = [](const char* p, int i) -> float {
+        if (DT == DT_F32) return reinterpret_cast<const float*>(p)[i];
+        return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p)[i] << 16);
+    };
     for (long row0 = (long)blockIdx.x * EX_ROWS; row0 < n; row0 += (long)gridDim.x * EX_ROWS) {
         double acc = 0.0;
         for (int k0 = 0; k0 < d; k0 += EX_KC) {
-            const int kc = d - k0 < EX_KC ? d - k0 : EX_KC;   // multiple of 4
-            const int nv = kc / 4;
+            const int kc = d - k0 < EX_KC ? d - k0 : EX_KC;   // multiple of EPV
+            const int nv = kc / EPV;
             __syncthreads();
             for (int i = lane; i < EX_ROWS * nv; i += 64) {
                 const int rr = i / nv, cc = i % nv;
                 long grow = row0 + rr;
                 if (grow > n - 1) grow = n - 1;
-                const float4 v = *reinterpret_cast<const float4*>(C + (size_t)grow * d + k0 + cc * 4);
-                *reinterpret_cast<float4*>(&tile[rr * EX_LD + cc * 4]) = v;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(C + ((size_t)grow * d + k0) * EB + cc * 16);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) tile[rr * EX_LD + cc * EPV + e] = to_f32(reinterpret_cast<const char*>(&v), e);
             }
-            for (int i = lane; i < kc; i += 64) qs[i] = q[k0 + i];
+            for (int i = lane; i < kc; i += 64) qs[i] = to_f32(q, k0 + i);
             __syncthreads();
             const float* mine = &tile[lane * EX_LD];
             if (metric == 0) {
@@ -100,11 +110,12 @@ __global__ __launch_bounds__(FULL_THREADS) void k_topk_full(const float* __restr
 
 size_t ip_topk_exhaustive_workspace_bytes(long nsel, long n) { return (size_t)nsel * n * 4 + 256; }
 
-int ip_topk_exhaustive(const float* q, const int* qsel, long nsel, const float* c, long n, int d,
-                       int k, long id_offset, int metric, float* D_out, long* I_out, void* ws,
+int ip_topk_exhaustive(const void* q, const int* qsel, long nsel, const void* c, long n, int d,
+                       int k, int dtype, long id_offset, int metric, float* D_out, long* I_out, void* ws,
                        size_t ws_bytes, hipStream_t st) {
-    if (nsel <= 0 || n <= 0 || k <= 0 || d <= 0 || d % 4 || (metric != 0 && metric != 1)) {
-        set_error("ip_topk_exhaustive: need nsel, n, k > 0, d %% 4 == 0, metric in {0,1}");
+    if (nsel <= 0 || n <= 0 || k <= 0 || d <= 0 || (dtype != DT_F32 && dtype != DT_BF16) ||
+        d % (dtype == DT_F32 ? 4 : 8) || (metric != 0 && metric != 1)) {
+        set_error("ip_topk_exhaustive: need nsel, n, k > 0, d %% 4 == 0 (f32) / d %% 8 == 0 (bf16), metric in {0,1}");
         return SSS_EINVAL;
     }
     if (n >= (1L << 31) || nsel > 65535) { set_error("ip_topk_exhaustive: n < 2^31, nsel <= 65535"); return SSS_EINVAL; }
@@ -115,7 +126,10 @@ int ip_topk_exhaustive(const float* q, const int* qsel, long nsel, const float* 
     float* scores = reinterpret_cast<float*>(ws);
     long gx = (n + EX_ROWS - 1) / EX_ROWS;
     if (gx > 8192) gx = 8192;
-    hipLaunchKernelGGL(k_exact_scores, dim3((unsigned)gx, (unsigned)nsel), dim3(64), 0, st, q, qsel, c, n, d, metric, scores);
+    if (dtype == DT_F32)
+        hipLaunchKernelGGL(k_exact_scores<DT_F32>, dim3((unsigned)gx, (unsigned)nsel), dim3(64), 0, st, q, qsel, c, n, d, metric, scores);
+    else
+        hipLaunchKernelGGL(k_exact_scores<DT_BF16>, dim3((unsigned)gx, (unsigned)nsel), dim3(64), 0, st, q, qsel, c, n, d, metric, scores);
     int rc = check_launch("k_exact_scores");
     if (rc) return rc;
     hipLaunchKernelGGL(k_topk_full, dim3((unsigned)nsel), dim3(FULL_THREADS), 0, st, scores, qsel, n, k, id_offset, metric, D_out, I_out);

@@ -9,6 +9,8 @@
 
 namespace sss {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
@@ -65,6 +67,45 @@ __global__ __launch_bounds__(256) void k_row_norm_max(const float* __restrict__ 
         atomicMax(reinterpret_cast<unsigned int*>(out), __builtin_bit_cast(unsigned int, sqrtf(m) * 1.0000002f));
 }
 
+// bf16 rows: max over rows of the 2-norm of the (exactly converted) float32 values
+__global__ __launch_bounds__(256) void k_row_norm_max_bf16(const unsigned short* __restrict__ x, long n, int d,
+                                                           float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    float m = 0.f;
+    for (long row = wave; row < n; row += nwaves) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(x + row * (long)d);
+        float ss = 0.f;
+        for (int i = lane; i < d / 8; i += 64) {
+            const u32x4 v = p[i];
+#define SSS_SQ2(w)                                                                   \
+    { const float lo = __builtin_bit_cast(float, v.w << 16), hi = __builtin_bit_cast(float, v.w & 0xFFFF0000u); \
+      ss += lo * lo + hi * hi; }
+            SSS_SQ2(x) SSS_SQ2(y) SSS_SQ2(z) SSS_SQ2(w)
+#undef SSS_SQ2
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        m = fmaxf(m, ss);
+    }
+    if (lane == 0)
+        atomicMax(reinterpret_cast<unsigned int*>(out), __builtin_bit_cast(unsigned int, sqrtf(m) * 1.0000002f));
+}
+
+// float32 -> bfloat16, round to nearest even (plain cast: v_cvt_pk_bf16_f32, NaN stays NaN);
+// 8 elements per thread, 32-byte loads / 16-byte stores.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ x, long n8, unsigned short* __restrict__ y) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+        bf16x8_t o;
+        o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)a.z; o[3] = (__bf16)a.w;
+        o[4] = (__bf16)b.x; o[5] = (__bf16)b.y; o[6] = (__bf16)b.z; o[7] = (__bf16)b.w;
+        reinterpret_cast<bf16x8_t*>(y)[i] = o;
+    }
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ table,
                                                      const long* __restrict__ ids, long n, int d,
@@ -115,12 +156,31 @@ int normalize_rows(float* x, long n, int d, long ld, float eps, int rule, hipStr
     return check_launch("k_normalize_rows");
 }
 
-int row_norm_max(const float* x, long n, int d, float* out, hipStream_t st) {
-    if (n < 0 || d <= 0 || d % 4) { set_error("row_norm_max: need n >= 0, d %% 4 == 0"); return SSS_EINVAL; }
+int row_norm_max(const void* xv, long n, int d, int dtype, float* out, hipStream_t st) {
+    if (dtype == 1) {
+        if (n < 0 || d <= 0 || d % 8) { set_error("row_norm_max: bf16 needs d %% 8 == 0"); return SSS_EINVAL; }
+        if (n == 0) return SSS_OK;
+        long blocks = (n + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_row_norm_max_bf16, dim3((unsigned)blocks), dim3(256), 0, st,
+                           reinterpret_cast<const unsigned short*>(xv), n, d, out);
+        return check_launch("k_row_norm_max_bf16");
+    }
+    const float* x = reinterpret_cast<const float*>(xv);
+    if (dtype != 0 || n < 0 || d <= 0 || d % 4) { set_error("row_norm_max: need dtype in {0,1}, n >= 0, d %% 4 == 0"); return SSS_EINVAL; }
     if (n == 0) return SSS_OK;
     const int lpr = lanes_per_row(d);
     SSS_DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_row_norm_max<L>, dim3(grid_for(n, L)), dim3(256), 0, st, x, n, d, out));
     return check_launch("k_row_norm_max");
+}
+
+int f32_to_bf16(const float* x, long count, unsigned short* y, hipStream_t st) {
+    if (count < 0 || count % 8) { set_error("f32_to_bf16: element count must be a multiple of 8"); return SSS_EINVAL; }
+    if (count == 0) return SSS_OK;
+    long blocks = (count / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)blocks), dim3(256), 0, st, x, count / 8, y);
+    return check_launch("k_f32_to_bf16");
 }
 
 int gather_rows(const float* table, const long* ids, long n, int d, float* out, long ld_out, hipStream_t st) {

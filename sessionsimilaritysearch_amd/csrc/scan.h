@@ -1,0 +1,64 @@
+// Internal interface between the scan kernel (scan.hip), the select / re-score kernels
+// (select.hip) and the host orchestration of sss_ip_topk (ip_topk.hip).  gfx950 only.
+#pragma once
+#include "sss_common.h"
+
+namespace sss {
+
+constexpr int DT_F32 = 0;       // element type codes of the C ABI (include/sss.h: dtype)
+constexpr int DT_BF16 = 1;
+
+constexpr int KP = 16;          // per-lane candidate list length (register resident)
+constexpr int WG_QUERIES = 256; // queries per scan workgroup (8 waves x 32)
+constexpr int MAX_SLOTS = 64;   // admission-threshold slots per query (J <= MAX_SLOTS)
+constexpr unsigned ORD_NEG_INF = 0x007FFFFFu;   // f2ord(-inf); slot value 0 = "never written"
+
+static inline int elem_bytes(int dtype) { return dtype == DT_BF16 ? 2 : 4; }
+
+// Per-search plan (host).  Workspace layout (all offsets 256-byte aligned):
+//   cand    u64 [nq][cap]   compacted candidate keys, cap = L * KP
+//   slots   u32 [nq][J]     admission-threshold slots (zeroed per call)
+//   cnt     u32 [nq]        candidates written per query (zeroed per call)
+//   maxlast u64 [nq]        largest tail key over FULL lane lists (zeroed per call)
+struct ScanPlan {
+    int G, S, L, K2, J, cert, boot, tile_rows;
+    int total_tiles, tiles_per_split, cap;
+    size_t off_cand, off_slots, off_cnt, off_maxlast, zero_begin, zero_bytes, total_bytes;
+};
+
+ScanPlan make_plan(long nq, long n, int d, int k, int dtype);
+
+struct ScanArgs {
+    const void* Q;
+    const void* C;
+    int nq, n, tiles_per_split, total_tiles, S, G, J, cert, boot, cap;
+    unsigned* slots;
+    unsigned* cnt;
+    unsigned long long* maxlast;
+    unsigned long long* cand;
+};
+
+int launch_scan(int dtype, int d, int tile_rows, const ScanArgs& a, hipStream_t st);
+
+struct SelectArgs {
+    const void* Q;
+    const void* C;
+    int nq, d, dtype, k, K2, J, cap;
+    const unsigned long long* cand;
+    const unsigned* cnt;
+    const unsigned long long* maxlast;
+    const unsigned* slots;
+    long id_offset;
+    float corpus_max_norm;
+    float* D_out;
+    long* I_out;
+    int* status;
+};
+
+int launch_select(const SelectArgs& a, hipStream_t st);
+
+// per-device one-time setup flags (hipFuncSetAttribute is per device)
+constexpr int MAX_DEVICES = 64;
+int current_device();
+
+}  // namespace sss

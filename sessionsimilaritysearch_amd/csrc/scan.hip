@@ -1,0 +1,446 @@
+// Query x corpus inner-product scan with fused running top-k (gfx950 / CDNA4), f32 and bf16.
+//
+// Replaces what the reference asks of faiss at test_amazon_filterd.py:578
+// (`D, I = index.search(normalize(emb), K)`, faiss.IndexFlatIP).
+//
+// k_scan<RB, TR, DT>  -- the dominant kernel (MFMA-bound, DESIGN.md "scoring kernel"); RB = bytes per
+// corpus row (256 / 512 / 1024), TR = rows per LDS tile, DT = element type:
+//   * one workgroup = 8 waves (2 per SIMD) = 256 queries x one contiguous corpus split;
+//   * each wave keeps its 32 queries resident in RB/8 VGPRs as the B operand of
+//     v_mfma_f32_32x32x2_f32 (DT_F32: an exact k-ordered f32 fma chain) or
+//     v_mfma_f32_32x32x16_bf16 (DT_BF16), so the query tile is read from HBM once;
+//   * corpus rows stream HBM -> LDS with global_load_lds_dwordx4 (no VGPR staging), double
+//     buffered, 16-byte chunks XOR-swizzled on the SOURCE address so the ds_read_b128 fragment
+//     reads are bank-conflict free.  A 512-byte f32 row (d=128) and a 512-byte bf16 row (d=256)
+//     stage and read identically: lane half h reads chunk 2u+h, which is the k-permuted A operand
+//     of four f32 MFMAs or the natural A operand of one bf16 MFMA;
+//   * the score matrix is never written: each lane owns one query column of the 32x32
+//     accumulator and keeps a sorted top-KP list (scores + row ids) in registers; the hot path is
+//     one v_max3 tree + one compare per 32x32 block;
+//   * ADMISSION THRESHOLD shared by all workgroups of a query (replaces round 1's sampled
+//     pre-pass kernels): every lane list belongs to one of J classes (J >= K2); slot[q][class]
+//     holds, by atomic max, the best score any list of that class has seen (cert == 1) or the
+//     largest cert-th best of such a list (cert > 1).  Classes partition the corpus rows, so
+//     tau = min over slots is a score that at least J * cert >= K2 distinct rows reach, and a row
+//     scoring below tau can never be among the best K2.  With cert == 1 the first tile of every
+//     split is scanned twice: once max-only to publish (bootstrap), and again at the end with
+//     the lists live, so no row is lost and the expensive "early phase" of a running top-k
+//     (every row beats an empty list) never happens.  Slots only ever hold scores of real rows
+//     and only grow, so a stale read merely admits extra candidates: speed, never correctness.
+//   * at the end each lane appends its real entries to the query's compact candidate array
+//     (one atomic add per lane) for k_select_* (select.hip).
+#include "scan.h"
+
+namespace sss {
+
+typedef char __attribute__((address_space(3)))* lptr_c;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Sorted (descending) insert of (x, id) into a register list; lanes whose x does not beat
+// their list tail fall through untouched.
+template <int N>
+__device__ __forceinline__ void list_insert(float (&ls)[N], int (&li)[N], float x, int id) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const bool c = x > ls[i];
+        const float ns = c ? x : ls[i];
+        const int ni = c ? id : li[i];
+        x = c ? ls[i] : x;
+        id = c ? li[i] : id;
+        ls[i] = ns;
+        li[i] = ni;
+    }
+}
+
+// Two 16-byte agent-scope (sc1: not served from this CU's L1) loads + their wait, as ONE asm
+// statement so the destinations are never touched before the data has landed.
+__device__ __forceinline__ unsigned min8_sc1(const unsigned* p) {
+    u32x4 a, b;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+    const unsigned m0 = min(min(a.x, a.y), min(a.z, a.w));
+    const unsigned m1 = min(min(b.x, b.y), min(b.z, b.w));
+    return min(m0, m1);
+}
+
+template <int RB, int TR, int DT>
+__global__ __launch_bounds__(512, 2) void k_scan(const ScanArgs A) {
+    constexpr int H = TR / 64;                        // 64-row sub-steps per tile
+    constexpr int CH = RB / 16;                       // 16-byte chunks per row
+    constexpr int NU = RB / 32;                       // k-groups per row (one b128 fragment each)
+    constexpr int TILE_BYTES = TR * RB;
+    constexpr int LOADS_PER_WAVE = TR * CH / 64 / 8;  // LDS-DMA wave-instructions per wave per tile
+    constexpr bool PRECOMP = RB <= 512;               // keep the DMA lane offsets in VGPRs (register budget)
+    static_assert(CH <= 64, "row longer than one LDS-DMA instruction");
+    static_assert(LOADS_PER_WAVE >= 1 && LOADS_PER_WAVE < NU, "DMA pieces must fit the k loop");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int nq = A.nq, n = A.n, S = A.S, G = A.G, J = A.J;
+    const char* __restrict__ Qb = reinterpret_cast<const char*>(A.Q);
+    const char* __restrict__ Cb = reinterpret_cast<const char*>(A.C);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware remap: blocks b and b+8 share an XCD (and its L2); the G query groups that
+    // stream the same corpus split are given consecutive slots of ONE XCD so the split is
+    // fetched from HBM once and re-read from that L2.  Speed only, never correctness.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int split = xcd * (S >> 3) + slot / G;
+    const int g = slot % G;
+
+    // ---- resident queries: lane (r, h) holds 16-byte chunk 2u + h of its query row in qc[u]
+    const int q_local = wave * 32 + r;
+    const int q_glob = g * WG_QUERIES + q_local;
+    const int q_ld = q_glob < nq ? q_glob : nq - 1;
+    f32x4 qc[NU];
+    {
+        const f32x4* qp = reinterpret_cast<const f32x4*>(Qb + (size_t)q_ld * RB) + h;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) qc[u] = qp[2 * u];
+        // retire the query loads HERE: otherwise hipcc sinks their counted vmcnt waits into the
+        // tile loop, where they would also wait on the (uncounted) LDS-DMA of the next tile.
+#pragma unroll
+        for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(qc[u]));
+    }
+
+    // Lane list, sorted descending; empty slots are (-inf, -1).  thr = max(list tail, tau) is the
+    // one value the hot path compares against.
+    float ls[KP];
+    int li[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) { ls[i] = -INFINITY; li[i] = -1; }
+    float pend_s = -INFINITY;   // one parked candidate per lane (see the epilogue)
+    int pend_i = -1;
+    float tau = -INFINITY, thr = -INFINITY;
+    float rmax = -INFINITY;     // best score this lane has seen (published when cert == 1)
+    float pub = -INFINITY;      // last value this lane published
+
+    int tile_lo = split * A.tiles_per_split;
+    int tile_hi = tile_lo + A.tiles_per_split;
+    if (tile_hi > A.total_tiles) tile_hi = A.total_tiles;
+    const int ntiles = tile_lo < tile_hi ? tile_hi - tile_lo : 0;
+    const bool use_tau = J > 0;
+    const bool boot = use_tau && A.boot && ntiles > 0;
+    const int niter = ntiles + (boot ? 1 : 0);
+    // iteration -> tile: with the bootstrap the first tile is scanned at iteration 0 (max only)
+    // and again at the last iteration (lists live)
+    auto tile_of = [&](int i) { return (boot && i == ntiles) ? tile_lo : tile_lo + i; };
+
+    unsigned* my_slot = nullptr;
+    const unsigned* my_half = nullptr;
+    if (use_tau) {
+        my_slot = A.slots + (size_t)q_ld * J + (unsigned)(2 * split + h) % (unsigned)J;
+        my_half = A.slots + (size_t)q_ld * J + h * (J >> 1);
+    }
+    // min over the query's J slots: each lane of the (h = 0, 1) pair reads half, 8 slots a step
+    auto tau_ord = [&]() -> unsigned {
+        unsigned m = 0xFFFFFFFFu;
+        for (int v = 0; v < (J >> 1); v += 8) m = min(m, min8_sc1(my_half + v));
+        return min(m, (unsigned)__shfl_xor((int)m, 32));
+    };
+    auto set_tau = [&](unsigned m) {
+        if (m > ORD_NEG_INF) tau = fmaxf(tau, ord2f(m - 1));     // the float just below the min slot
+        thr = fmaxf(ls[KP - 1], tau);
+    };
+    auto publish = [&]() {
+        float val = rmax;
+        bool ok = true;
+        if (A.cert > 1) {
+            // copies made opaque: a select chain over ls[] / li[] would be folded into a
+            // runtime-indexed load and send both lists to scratch
+            float v2 = ls[1], v4 = ls[3], v8 = ls[7], v16 = ls[KP - 1];
+            int i2 = li[1], i4 = li[3], i8 = li[7], i16 = li[KP - 1];
+            asm volatile("" : "+v"(v2), "+v"(v4), "+v"(v8), "+v"(v16), "+v"(i2), "+v"(i4), "+v"(i8), "+v"(i16));
+            const int c = A.cert;
+            val = c == 2 ? v2 : c == 4 ? v4 : c == 8 ? v8 : v16;
+            ok = (c == 2 ? i2 : c == 4 ? i4 : c == 8 ? i8 : i16) >= 0;
+        }
+        if (ok && val > pub && q_glob < nq) {
+            __hip_atomic_fetch_max(my_slot, f2ord(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pub = val;
+        }
+    };
+
+    // LDS-DMA staging (global_load_lds_dwordx4, 1 KiB per wave-instruction).  Written as inline
+    // asm so hipcc neither counts it nor drains vmcnt(0) at the next ds_read: the next tile
+    // stays in flight under this tile's MFMAs and is retired by the explicit vmcnt(0) that
+    // precedes the barrier at the end of the iteration (cdna_hip_programming.md section 5.7).
+    // Slot p of the tile (16 B each) holds chunk (p % CH) ^ (row & 15) of row p / CH: the
+    // swizzle is on the SOURCE address, the LDS image is lane-linear.
+    const unsigned lds_base = (unsigned)(unsigned long)(lptr_c)smem;
+    auto slot_row = [&](int i) { return ((wave * LOADS_PER_WAVE + i) * 64 + lane) / CH; };
+    auto slot_off = [&](int i) {                    // byte offset of this lane's chunk inside the tile
+        const int p = (wave * LOADS_PER_WAVE + i) * 64 + lane;
+        const int tr = p / CH, sc = p % CH;
+        return (unsigned)(tr * RB + ((sc ^ (tr & 15)) * 16));
+    };
+    unsigned lane_off[PRECOMP ? LOADS_PER_WAVE : 1];
+    if (PRECOMP) {
+#pragma unroll
+        for (int i = 0; i < LOADS_PER_WAVE; ++i) lane_off[i] = slot_off(i);
+    }
+    // One LDS-DMA wave-instruction (piece i of this wave's share of a tile).
+    auto stage_piece = [&](int buf, int tile_idx, int i) {
+        const long row0 = (long)tile_idx * TR;
+        const bool inside = row0 + TR <= (long)n;          // wave-uniform
+        const char* tile_src = Cb + (size_t)row0 * RB;      // wave-uniform -> SGPR pair
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            lds_base + buf * TILE_BYTES + (wave * LOADS_PER_WAVE + i) * 1024);
+        unsigned off = PRECOMP ? lane_off[PRECOMP ? i : 0] : slot_off(i);
+        if (!inside) {                                       // ragged last tile: clamp the row
+            const int lr = slot_row(i);
+            long grow = row0 + lr;
+            if (grow > (long)n - 1) grow = (long)n - 1;
+            off = (unsigned)((grow - row0) * RB) + (off - (unsigned)(lr * RB));
+        }
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(dst), "s"(tile_src) : "memory");
+    };
+    auto stage = [&](int buf, int tile_idx) {
+#pragma unroll
+        for (int i = 0; i < LOADS_PER_WAVE; ++i) stage_piece(buf, tile_idx, i);
+    };
+
+    // per-lane LDS read swizzle term of chunk (2u + h) of row r
+    const int x = h ^ (r & 15);
+    f32x16 acc0 = {0}, acc1 = {0};
+
+    auto mfma_sub = [&](int buf, int sub, int next_tile) {
+        const char* tile = smem + buf * TILE_BYTES + sub * (64 * RB);
+        auto lda = [&](int u, int mb) -> f32x4 {
+            const int c = (2 * u) ^ x;                          // == (2u + h) ^ (r & 15)
+            return *reinterpret_cast<const f32x4*>(tile + ((r + 32 * mb) * CH + c) * 16);
+        };
+        f32x4 a0 = lda(0, 0), a1 = lda(0, 1);
+        const f32x16 zero = {0};
+        acc0 = zero; acc1 = zero;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            f32x4 n0 = a0, n1 = a1;
+            if (u + 1 < NU) { n0 = lda(u + 1, 0); n1 = lda(u + 1, 1); }   // one k-group ahead
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE this group's MFMAs
+            if constexpr (DT == DT_F32) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, qc[u].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, qc[u].x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, qc[u].y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, qc[u].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, qc[u].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, qc[u].z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, qc[u].w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, qc[u].w, acc1, 0, 0, 0);
+            } else {
+                const bf16x8 qb = __builtin_bit_cast(bf16x8, qc[u]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), qb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), qb, acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = n0; a1 = n1;
+            // one DMA piece per k-group: each issue hides under the MFMAs this wave just queued
+            if (u >= 1 && u - 1 < LOADS_PER_WAVE && next_tile >= 0) {
+                stage_piece(buf ^ 1, next_tile, u - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    auto block_max = [&](const f32x16& a, float& q0, float& q1, float& q2, float& q3) {
+        q0 = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+        q1 = fmaxf(fmaxf(a[4], a[5]), fmaxf(a[6], a[7]));
+        q2 = fmaxf(fmaxf(a[8], a[9]), fmaxf(a[10], a[11]));
+        q3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
+        return fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
+    };
+    // Top-k epilogue of one 32x32 accumulator: a[j] is (corpus row base + (j&3) + 8*(j>>2), query r).
+    // Hot path: quarter maxima (rows 8g..8g+3 of this lane's 16) + one compare.  When some lane's
+    // maximum beats its threshold, only the quarters that hold a passing score are walked.
+    auto epilogue_block = [&](const f32x16& a, int base) {
+        float q0, q1, q2, q3;
+        const float m = block_max(a, q0, q1, q2, q3);
+        rmax = fmaxf(rmax, m);
+        if (__builtin_amdgcn_ballot_w64(m > thr) == 0) return;
+        // A passing score parks in the lane's one pending slot; the 80-instruction sorted insert
+        // runs only when some lane needs its slot again (then every lane's pending entry goes in
+        // with that same pass).  thr may therefore lag behind -- it only admits extra
+        // candidates, never drops one.
+        auto walk = [&](float qm, int j0) {
+            if (__builtin_amdgcn_ballot_w64(qm > thr) == 0) return;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = j0 + jj;
+                const bool pass = a[j] > thr;
+                if (__builtin_amdgcn_ballot_w64(pass) != 0) {
+                    if (__builtin_amdgcn_ballot_w64(pass && pend_i >= 0) != 0) {
+                        list_insert<KP>(ls, li, pend_s, pend_i);
+                        pend_s = -INFINITY; pend_i = -1;
+                        thr = fmaxf(ls[KP - 1], tau);
+                    }
+                    const bool still = a[j] > thr;
+                    pend_s = still ? a[j] : pend_s;
+                    pend_i = still ? base + (j & 3) + 8 * (j >> 2) : pend_i;
+                }
+            }
+        };
+        walk(q0, 0); walk(q1, 4); walk(q2, 8); walk(q3, 12);     // ascending row order per lane
+    };
+
+    if (ntiles > 0) stage(0, tile_lo);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int i = 0; i < niter; ++i) {
+        const int buf = i & 1;
+        const bool pre = boot && i == 0;
+        if (use_tau && i > 0) {
+            // Threshold refresh: synchronous loads, staggered between the two waves of a SIMD
+            // (waves 4-7 one tile later) so the partner keeps the matrix pipe busy meanwhile.
+            const int ii = i - (wave >= 4 ? 1 : 0);
+            if (ii >= 2 && (ii <= 8 || (ii & (ii - 1)) == 0 || (ii & 15) == 0)) set_tau(tau_ord());
+            publish();      // completes under this tile's MFMAs
+        }
+        const int t_cur = tile_of(i);
+        for (int sub = 0; sub < H; ++sub) {
+            const int next_tile = (sub == 0 && i + 1 < niter) ? tile_of(i + 1) : -1;
+            mfma_sub(buf, sub, next_tile);
+            // acc[j] is (corpus row base + (j&3) + 8*(j>>2) + 4h, query r)
+            const long sub_row0 = (long)t_cur * TR + sub * 64;
+            if (sub_row0 + 64 > n) {                        // wave-uniform, last tile only
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int rr = (int)sub_row0 + 4 * h + (j & 3) + 8 * (j >> 2);
+                    if (rr >= n) acc0[j] = -INFINITY;
+                    if (rr + 32 >= n) acc1[j] = -INFINITY;
+                }
+            }
+            if (pre) {                                      // bootstrap: lane maximum only
+                float q0, q1, q2, q3;
+                rmax = fmaxf(rmax, block_max(acc0, q0, q1, q2, q3));
+                rmax = fmaxf(rmax, block_max(acc1, q0, q1, q2, q3));
+            } else {
+                epilogue_block(acc0, (int)sub_row0 + 4 * h);
+                epilogue_block(acc1, (int)sub_row0 + 32 + 4 * h);
+            }
+        }
+        if (pre) publish();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile landed
+        __syncthreads();                                   // ... everyone's did, and this buffer is free
+        if (pre) {
+            // Wait (bounded) until every class of this wave's queries has published its bootstrap
+            // maximum.  All workgroups of a launch are normally co-resident and reach this point
+            // within a microsecond of each other; if not, the bound expires and the scan simply
+            // runs with a weaker (or no) threshold -- correctness never depends on it.
+            unsigned m = 0;
+            for (int it = 0; it < 24; ++it) {
+                m = tau_ord();
+                if (__builtin_amdgcn_ballot_w64(m == 0) == 0) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+            set_tau(m);
+        }
+    }
+
+    list_insert<KP>(ls, li, pend_s, pend_i);   // no-op for lanes with an empty slot (-inf)
+    // ---- append the real entries to the query's compact candidate array
+    if (q_glob < nq) {
+        int nreal = 0;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) nreal += li[i] >= 0 ? 1 : 0;
+        if (nreal > 0) {
+            const unsigned base = atomicAdd(A.cnt + q_glob, (unsigned)nreal);
+            unsigned long long* dst = A.cand + (size_t)q_glob * A.cap + base;
+#pragma unroll
+            for (int i = 0; i < KP; ++i)
+                if (i < nreal) dst[i] = make_key(ls[i], li[i]);
+            if (nreal == KP) atomicMax(A.maxlast + q_glob, (unsigned long long)make_key(ls[KP - 1], li[KP - 1]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+int current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev < 0 || dev >= MAX_DEVICES ? 0 : dev;
+}
+
+static int pick_splits(long n, int G, int tr) {
+    // S*G workgroups, one per CU (256 CUs); S a multiple of 8 (XCD remap); >= one tile a split.
+    int S = (256 / G) & ~7;
+    if (S < 8) S = 8;
+    while (S > 8 && (long)S * tr > n) S -= 8;
+    return S;
+}
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
+    ScanPlan p;
+    const int rb = d * elem_bytes(dtype);
+    p.G = (int)((nq + WG_QUERIES - 1) / WG_QUERIES);
+    // 128-row tiles (one barrier per 128 rows) for long splits; 64-row tiles keep the split
+    // granularity (and the once-repeated bootstrap tile) small when a split is only a few tiles.
+    int tr = rb <= 512 ? 128 : 64;
+    int S = pick_splits(n, p.G, tr);
+    if (rb == 512 && (n + (long)S * 128 - 1) / ((long)S * 128) < 48) { tr = 64; S = pick_splits(n, p.G, tr); }
+    p.tile_rows = tr;
+    p.S = S;
+    p.L = 2 * S;
+    p.K2 = k + (k <= 12 ? KP - k : 12);
+    if ((long)p.L * KP < p.K2) p.K2 = p.L * KP;
+    p.total_tiles = (int)((n + tr - 1) / tr);
+    p.tiles_per_split = (p.total_tiles + S - 1) / S;
+    p.cap = p.L * KP;
+    // threshold slots: J classes x cert entries certify J * cert >= K2 rows (scan.hip header)
+    p.J = p.K2 <= 128 ? 16 : MAX_SLOTS;
+    p.cert = 1;
+    while (p.J * p.cert < p.K2 && p.cert < KP) p.cert *= 2;
+    const int active_splits = (p.total_tiles + p.tiles_per_split - 1) / p.tiles_per_split;
+    if (p.J * p.cert < p.K2 || 2 * active_splits < p.J) p.J = 0;      // tiny corpus: no threshold
+    p.boot = (p.J > 0 && p.cert == 1) ? 1 : 0;
+    p.off_cand = 0;
+    p.off_slots = align256((size_t)nq * p.cap * 8);
+    p.off_cnt = align256(p.off_slots + (size_t)nq * MAX_SLOTS * 4);
+    p.off_maxlast = align256(p.off_cnt + (size_t)nq * 4);
+    p.total_bytes = align256(p.off_maxlast + (size_t)nq * 8);
+    p.zero_begin = p.off_slots;
+    p.zero_bytes = p.total_bytes - p.off_slots;
+    return p;
+}
+
+template <int RB, int TR, int DT>
+static int launch_one(const ScanArgs& a, hipStream_t st) {
+    const size_t lds = 2 * (size_t)TR * RB;
+    static bool attr_done[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!attr_done[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<RB, TR, DT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL((k_scan<RB, TR, DT>), dim3(a.S * a.G), dim3(512), lds, st, a);
+    return check_launch("k_scan");
+}
+
+int launch_scan(int dtype, int d, int tile_rows, const ScanArgs& a, hipStream_t st) {
+    const int rb = d * elem_bytes(dtype);
+    if (dtype == DT_F32) {
+        if (rb == 256) return launch_one<256, 128, DT_F32>(a, st);
+        if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_F32>(a, st) : launch_one<512, 64, DT_F32>(a, st);
+        if (rb == 1024) return launch_one<1024, 64, DT_F32>(a, st);
+    } else {
+        if (rb == 256) return launch_one<256, 128, DT_BF16>(a, st);
+        if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_BF16>(a, st) : launch_one<512, 64, DT_BF16>(a, st);
+        if (rb == 1024) return launch_one<1024, 64, DT_BF16>(a, st);
+    }
+    set_error("scan: unsupported row size %d bytes", rb);
+    return SSS_EINVAL;
+}
+
+}  // namespace sss

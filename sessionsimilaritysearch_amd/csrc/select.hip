@@ -1,0 +1,364 @@
+// Candidate selection + canonical float64 re-score + proof of exactness, and the k-way merge of
+// per-shard results (gfx950).  Second half of what the reference asks of faiss at
+// test_amazon_filterd.py:578 (the per-query heap inside IndexFlatIP.search).
+//
+// Input: the compact candidate keys k_scan (scan.hip) appended per query.  Per query:
+//   select the best K2 = k + slack candidates by (float32 score desc, id asc), re-score them in
+//   float64 in the canonical sequential order (== the oracle's score), order by
+//   (score desc, id asc), write the first k, and decide
+//   status[q] = 0  proven exact: every row that was NOT re-scored has a float32 score at or
+//                  below the selection edge (it lost to a full list's tail <= edge, or to the
+//                  admission threshold < edge, or it is a candidate ranked below the edge), and
+//                  edge + 2B < k-th re-scored score, B bounding the scan's rounding error;
+//             = 1  not proven -> the caller re-runs the query through the exhaustive path.
+//   k_select_fast  : one wave per query, K2 <= 32, candidates <= FS_CAP (the common case: the
+//                    shared threshold leaves a few hundred candidates per query)
+//   k_select_sort  : one workgroup per query, bitonic sort in LDS, any K2 <= SEL_MAX_K2
+#include "scan.h"
+
+namespace sss {
+
+constexpr int FS_CAP = 1024;       // candidates a wave stages in LDS (more -> unproven)
+constexpr int FS_ROWS = 16;        // rows re-scored per pass
+constexpr int FS_K2 = 32;
+constexpr int SEL_MAX_K2 = 512;
+constexpr int SORT_THREADS = 256;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(v, o);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
+// Cross-lane hand-off through LDS inside ONE wave: the hardware runs a wave's LDS instructions in
+// order; this only stops the compiler from moving memory operations across the point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// acc += sum over the elements of one 16-byte chunk (4 f32 or 8 bf16), sequential in k
+__device__ __forceinline__ double dot_chunk(double acc, const char* qrow, int v, f32x4 c, int dtype) {
+    if (dtype == DT_F32) {
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow + v * 16);
+        acc += (double)qv.x * (double)c.x;
+        acc += (double)qv.y * (double)c.y;
+        acc += (double)qv.z * (double)c.z;
+        acc += (double)qv.w * (double)c.w;
+        return acc;
+    }
+    const u32x4 cu = __builtin_bit_cast(u32x4, c);
+    const u32x4 qu = *reinterpret_cast<const u32x4*>(qrow + v * 16);
+#define SSS_BF2(w)                                                                                              \
+    acc += (double)__builtin_bit_cast(float, qu.w << 16) * (double)__builtin_bit_cast(float, cu.w << 16);      \
+    acc += (double)__builtin_bit_cast(float, qu.w & 0xFFFF0000u) * (double)__builtin_bit_cast(float, cu.w & 0xFFFF0000u);
+    SSS_BF2(x) SSS_BF2(y) SSS_BF2(z) SSS_BF2(w)
+#undef SSS_BF2
+    return acc;
+}
+
+__device__ __forceinline__ float elem_to_f32(const void* row, int kk, int dtype) {
+    if (dtype == DT_F32) return reinterpret_cast<const float*>(row)[kk];
+    const unsigned short b = reinterpret_cast<const unsigned short*>(row)[kk];
+    return __builtin_bit_cast(float, (unsigned)b << 16);          // bf16 -> f32 is exact
+}
+
+// B = rounding-error bound of the scan's score of any row: f32 MFMA = k-ordered fma chain,
+// d * 2^-24 * |q| |c|; the bf16 MFMA sums exact products in f32 with unspecified internal
+// order/truncation: twice that.
+__device__ __forceinline__ double err_bound(int d, int dtype, double qnorm, double cmax) {
+    const double u = dtype == DT_F32 ? 5.9604644775390625e-08 : 1.1920928955078125e-07;
+    return (double)d * u * qnorm * cmax * 1.02;
+}
+
+// min over the J threshold slots of query q as an ordered-uint (0: some class never published)
+__device__ __forceinline__ unsigned final_tau_ord(const unsigned* slots, int J, int lane) {
+    unsigned m = 0xFFFFFFFFu;
+    for (int j = lane; j < J; j += 64) m = min(m, slots[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor((int)m, o));
+    return m;
+}
+
+struct Verdict { int st; };
+
+// Shared tail: rank the K2 re-scored candidates, write results, decide the status.  Called by
+// the threads [0, nthreads) of one query with sel/resc in LDS; lane0 writes the status.
+template <int NT>
+__device__ __forceinline__ void rank_and_write(const unsigned long long* sel, const double* resc, int K2, int k,
+                                               long id_offset, float* Dq, long* Iq, int t, int* s_nvalid,
+                                               double* s_kth) {
+    for (int c = t; c < K2; c += NT) {
+        const unsigned long long key = sel[c];
+        const int id = key_id(key);
+        if (key == 0 || id < 0) continue;
+        const float sc = (float)resc[c];
+        int rank = 0;
+        for (int j = 0; j < K2; ++j) {
+            const int idj = key_id(sel[j]);
+            if (j == c || sel[j] == 0 || idj < 0) continue;
+            const float sj = (float)resc[j];
+            if (sj > sc || (sj == sc && idj < id)) ++rank;
+        }
+        atomicAdd(s_nvalid, 1);
+        if (rank < k) { Dq[rank] = sc; Iq[rank] = (long)id + id_offset; }
+        if (rank == k - 1) *s_kth = resc[c];
+    }
+}
+
+__device__ __forceinline__ int decide_status(unsigned long long edge, unsigned long long maxlast, unsigned tau_o,
+                                             int J, int nvalid, int k, double kth, double B) {
+    int st = 0;
+    const bool edge_real = edge != 0 && key_id(edge) >= 0;
+    if (maxlast > edge) st = 1;                                   // a full list may hide a contender
+    if (J > 0 && tau_o > ORD_NEG_INF) {                           // rows were rejected at or below ord2f(tau_o - 1)
+        if (!(edge_real && f2ord(key_score(edge)) >= tau_o)) st = 1;
+    }
+    if (edge_real && nvalid >= k) {
+        if ((double)key_score(edge) + 2.0 * B >= kth) st = 1;     // float32 near-tie window reaches the edge
+    }
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------
+// One wave per query.  LDS per wave: keys[FS_CAP] | sel[FS_K2] | resc[FS_K2] | qrow[RBmax] | rows
+__global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wv;
+    if (q >= A.nq) return;                                        // whole wave; no block-level sync below
+    const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
+    const int ldrow = rb + 16;
+    const size_t per_wave = (size_t)FS_CAP * 8 + FS_K2 * 16 + 16 + rb + (size_t)FS_ROWS * ldrow;
+    char* base = smem + wv * ((per_wave + 15) & ~(size_t)15);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(base);
+    unsigned long long* sel = keys + FS_CAP;
+    double* resc = reinterpret_cast<double*>(sel + FS_K2);
+    int* s_nvalid = reinterpret_cast<int*>(resc + FS_K2);
+    double* s_kth = reinterpret_cast<double*>(s_nvalid + 2);
+    char* qrow = reinterpret_cast<char*>(s_kth + 1);
+    char* rows = qrow + rb;
+
+    const int K2 = A.K2, k = A.k;
+    float* Dq = A.D_out + (size_t)q * k;
+    long* Iq = A.I_out + (size_t)q * k;
+    const int M = (int)A.cnt[q];
+    if (M > FS_CAP) {                                             // adversarial input: let the exhaustive path decide
+        if (lane == 0) A.status[q] = 1;
+        return;
+    }
+    // ---- stage keys and the query row; per-lane best of keys lane, lane+64, ...
+    const unsigned long long* ck = A.cand + (size_t)q * A.cap;
+    unsigned long long best = 0; int bidx = -1;
+    for (int i = lane; i < M; i += 64) {
+        const unsigned long long v = ck[i];
+        keys[i] = v;
+        if (v > best) { best = v; bidx = i; }
+    }
+    for (int i = lane; i < rb / 16; i += 64)
+        reinterpret_cast<f32x4*>(qrow)[i] = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.Q) + (size_t)q * rb)[i];
+    if (lane == 0) { *s_nvalid = 0; *s_kth = 0.0; }
+    wave_sync();
+    // ---- K2 rounds: wave-wide arg-max, the owner lane retires its key and rescans its column
+    for (int it = 0; it < K2; ++it) {
+        const unsigned long long w = wave_max_u64(best);
+        if (lane == 0) sel[it] = w;
+        if (w != 0 && best == w) {                                // keys of real candidates are unique
+            keys[bidx] = 0;
+            best = 0; bidx = -1;
+            for (int i = lane; i < M; i += 64) {
+                const unsigned long long v = keys[i];
+                if (v > best) { best = v; bidx = i; }
+            }
+        }
+    }
+    // ---- float64 re-score, FS_ROWS candidates per pass: rows staged with coalesced 16-byte
+    // loads, then one lane per candidate walks k sequentially (the canonical order)
+    const int nv = rb / 16;
+    double qn2 = 0.0;
+    wave_sync();
+    for (int c0 = 0; c0 < K2; c0 += FS_ROWS) {
+        for (int i = lane; i < FS_ROWS * nv; i += 64) {
+            const int c = c0 + i / nv, v = i % nv;
+            const unsigned long long key = c < K2 ? sel[c] : 0;
+            const int id = key_id(key);
+            if (key != 0 && id >= 0)
+                *reinterpret_cast<f32x4*>(rows + (size_t)(i / nv) * ldrow + v * 16) =
+                    *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.C) + (size_t)id * rb + v * 16);
+        }
+        wave_sync();
+        if (lane < FS_ROWS && c0 + lane < K2) {
+            const unsigned long long key = sel[c0 + lane];
+            double acc = 0.0;
+            if (key != 0 && key_id(key) >= 0) {
+                const char* row = rows + (size_t)lane * ldrow;
+                for (int v = 0; v < nv; ++v)
+                    acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
+            }
+            resc[c0 + lane] = acc;
+        }
+        wave_sync();
+    }
+    if (lane == 0) {
+        for (int kk = 0; kk < A.d; ++kk) { const double v = elem_to_f32(qrow, kk, A.dtype); qn2 += v * v; }
+    }
+    rank_and_write<64>(sel, resc, K2, k, A.id_offset, Dq, Iq, lane, s_nvalid, s_kth);
+    wave_sync();
+    const int nvalid = *s_nvalid;
+    for (int j = nvalid + lane; j < k; j += 64) {                 // faiss pads missing results
+        Dq[j] = -3.4028234663852886e38f;
+        Iq[j] = -1;
+    }
+    const unsigned tau_o = A.J > 0 ? final_tau_ord(A.slots + (size_t)q * A.J, A.J, lane) : 0u;
+    if (lane == 0) {
+        const double B = err_bound(A.d, A.dtype, sqrt(qn2), (double)A.corpus_max_norm);
+        A.status[q] = decide_status(sel[K2 - 1], A.maxlast[q], tau_o, A.J, nvalid, k, *s_kth, B);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One workgroup per query: bitonic sort (descending) of the candidate keys in LDS.
+__global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A, int cap_pow2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);             // [cap_pow2]
+    double* resc = reinterpret_cast<double*>(keys + cap_pow2);                           // [SEL_MAX_K2]
+    char* qrow = reinterpret_cast<char*>(resc + SEL_MAX_K2);
+    __shared__ int s_nvalid;
+    __shared__ double s_kth;
+    __shared__ double s_q2[SORT_THREADS / 64];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
+    const int K2 = A.K2, k = A.k;
+    float* Dq = A.D_out + (size_t)q * k;
+    long* Iq = A.I_out + (size_t)q * k;
+    const int M = (int)A.cnt[q];
+    int M2 = 64;
+    while (M2 < M || M2 < K2) M2 <<= 1;                            // <= cap_pow2 by construction
+    const unsigned long long* ck = A.cand + (size_t)q * A.cap;
+    for (int i = tid; i < M2; i += SORT_THREADS) keys[i] = i < M ? ck[i] : 0ull;
+    for (int i = tid; i < rb / 16; i += SORT_THREADS)
+        reinterpret_cast<f32x4*>(qrow)[i] = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.Q) + (size_t)q * rb)[i];
+    if (tid == 0) { s_nvalid = 0; s_kth = 0.0; }
+    __syncthreads();
+    for (int kk = 2; kk <= M2; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < M2; i += SORT_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], b = keys[ixj];
+                    const bool desc = (i & kk) == 0;
+                    if (desc ? a < b : a > b) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- float64 re-score straight from global (one thread per candidate, sequential in k)
+    double q2 = 0.0;
+    for (int kx = tid; kx < A.d; kx += SORT_THREADS) { const double v = elem_to_f32(qrow, kx, A.dtype); q2 += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
+    if (lane == 0) s_q2[tid >> 6] = q2;
+    for (int c = tid; c < K2; c += SORT_THREADS) {
+        const unsigned long long key = keys[c];
+        const int id = key_id(key);
+        double acc = 0.0;
+        if (key != 0 && id >= 0) {
+            const char* row = reinterpret_cast<const char*>(A.C) + (size_t)id * rb;
+            for (int v = 0; v < rb / 16; ++v)
+                acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
+        }
+        resc[c] = acc;
+    }
+    __syncthreads();
+    rank_and_write<SORT_THREADS>(keys, resc, K2, k, A.id_offset, Dq, Iq, tid, &s_nvalid, &s_kth);
+    __syncthreads();
+    const int nvalid = s_nvalid;
+    for (int j = nvalid + tid; j < k; j += SORT_THREADS) {
+        Dq[j] = -3.4028234663852886e38f;
+        Iq[j] = -1;
+    }
+    if (tid < 64) {
+        const unsigned tau_o = A.J > 0 ? final_tau_ord(A.slots + (size_t)q * A.J, A.J, lane) : 0u;
+        if (tid == 0) {
+            double qq = 0.0;
+            for (int w = 0; w < SORT_THREADS / 64; ++w) qq += s_q2[w];
+            const double B = err_bound(A.d, A.dtype, sqrt(qq), (double)A.corpus_max_norm);
+            A.status[q] = decide_status(keys[K2 - 1], A.maxlast[q], tau_o, A.J, nvalid, k, s_kth, B);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k-way merge of per-shard results (after the RCCL all-gather): [shards][nq][k] -> [nq][k] by
+// (score desc, id asc); ids < 0 are padding.  One thread per query (k*shards is tiny).
+__global__ void k_topk_merge(const float* __restrict__ D_in, long d_stride, const long* __restrict__ I_in,
+                             long i_stride, int shards, int nq, int k, float* __restrict__ D_out,
+                             long* __restrict__ I_out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int pos[64];
+    for (int s = 0; s < shards; ++s) pos[s] = 0;
+    for (int o = 0; o < k; ++o) {
+        int bs = -1; float bd = 0.f; long bi = 0;
+        for (int s = 0; s < shards; ++s) {
+            if (pos[s] >= k) continue;
+            const size_t a = (size_t)q * k + pos[s];
+            const long id = I_in[(size_t)s * i_stride + a];
+            if (id < 0) { pos[s] = k; continue; }
+            const float dd = D_in[(size_t)s * d_stride + a];
+            if (bs < 0 || dd > bd || (dd == bd && id < bi)) { bs = s; bd = dd; bi = id; }
+        }
+        if (bs < 0) { D_out[(size_t)q * k + o] = -3.4028234663852886e38f; I_out[(size_t)q * k + o] = -1; }
+        else { D_out[(size_t)q * k + o] = bd; I_out[(size_t)q * k + o] = bi; ++pos[bs]; }
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+int launch_select(const SelectArgs& a, hipStream_t st) {
+    const int rb = a.d * elem_bytes(a.dtype);
+    const int dev = current_device();
+    if (a.K2 <= FS_K2) {
+        const size_t per_wave = (((size_t)FS_CAP * 8 + FS_K2 * 16 + 16 + rb + (size_t)FS_ROWS * (rb + 16)) + 15) & ~(size_t)15;
+        const size_t lds = 4 * per_wave;
+        static bool done[MAX_DEVICES] = {};
+        if (!done[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_fast),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+            done[dev] = true;
+        }
+        hipLaunchKernelGGL(k_select_fast, dim3((unsigned)((a.nq + 3) / 4)), dim3(256), lds, st, a);
+        return check_launch("k_select_fast");
+    }
+    if (a.K2 > SEL_MAX_K2) { set_error("select: K2 %d > %d", a.K2, SEL_MAX_K2); return SSS_EINVAL; }
+    int cap_pow2 = 64;
+    while (cap_pow2 < a.cap || cap_pow2 < a.K2) cap_pow2 <<= 1;
+    const size_t lds = (size_t)cap_pow2 * 8 + SEL_MAX_K2 * 8 + rb;
+    if (lds > 150 * 1024) { set_error("select: candidate capacity %d too large", a.cap); return SSS_EINVAL; }
+    static bool done2[MAX_DEVICES] = {};
+    if (!done2[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_sort),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        done2[dev] = true;
+    }
+    hipLaunchKernelGGL(k_select_sort, dim3((unsigned)a.nq), dim3(SORT_THREADS), lds, st, a, cap_pow2);
+    return check_launch("k_select_sort");
+}
+
+int topk_merge(const float* D_in, long d_stride, const long* I_in, long i_stride, int shards, long nq, int k,
+               float* D_out, long* I_out, hipStream_t st) {
+    if (shards < 1 || shards > 64 || nq <= 0 || k <= 0 || d_stride < nq * k || i_stride < nq * k) {
+        set_error("topk_merge: bad arguments");
+        return SSS_EINVAL;
+    }
+    hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)((nq + 127) / 128)), dim3(128), 0, st, D_in, d_stride, I_in,
+                       i_stride, shards, (int)nq, k, D_out, I_out);
+    return check_launch("k_topk_merge");
+}
+
+}  // namespace sss

@@ -19,8 +19,9 @@ import torch
 
 from . import _lib
 
-FUSED_DIMS = (64, 128, 256)
-FUSED_MAX_K = 116
+FUSED_DIMS = {"f32": (64, 128, 256), "bf16": (128, 256, 512)}   # row bytes 256 / 512 / 1024
+FUSED_MAX_K = 500
+DTYPE_CODE = {"f32": 0, "bf16": 1}                               # include/sss.h: dtype
 _EXHAUSTIVE_WS_BYTES = 1 << 30
 
 
@@ -41,6 +42,17 @@ def _as_device_f32(x, device):
     if not isinstance(x, torch.Tensor):
         raise TypeError("expected a numpy array or torch tensor")
     return x.to(device=device, dtype=torch.float32).contiguous()
+
+
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    """float32 CUDA tensor -> bfloat16 (round to nearest even) through ``sss_f32_to_bf16``."""
+    _lib.require_cuda(x, "x", torch.float32)
+    if x.numel() % 8:
+        raise _lib.SssError("to_bf16: element count must be a multiple of 8")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    rc = _lib.lib().sss_f32_to_bf16(x.data_ptr(), x.numel(), y.data_ptr(), _lib.stream_ptr(x.device))
+    _lib.check(rc, "sss_f32_to_bf16")
+    return y
 
 
 def normalize_(x: torch.Tensor, eps: float = 1e-6, rule: int = 0) -> torch.Tensor:
@@ -80,15 +92,26 @@ def normalize(vec, eps: float = 1e-6, rule: int = 0):
 class FlatIndex:
     """Exact flat index (faiss ``IndexFlatIP`` / ``IndexFlatL2`` semantics) with
     the canonical result contract of DESIGN.md: scores are float64-accumulated dot products
-    rounded to float32, ordered by (score desc, id asc); missing results are (-FLT_MAX, -1)."""
+    rounded to float32, ordered by (score desc, id asc); missing results are (-FLT_MAX, -1).
 
-    def __init__(self, d: int, metric: str = "ip", device=None):
+    ``dtype="bf16"`` (BASELINE config C5) stores the corpus -- and rounds every query -- to
+    bfloat16 and scores on the bf16 MFMA; the contract is then defined on the ROUNDED vectors
+    (float64 dot of the stored bf16 values)."""
+
+    def __init__(self, d: int, metric: str = "ip", device=None, dtype: str = "f32"):
         if metric not in ("ip", "l2"):
             raise ValueError("metric must be 'ip' or 'l2'")
+        if dtype not in DTYPE_CODE:
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        if dtype == "bf16" and d % 8:
+            raise ValueError("bf16 index needs d % 8 == 0")
         self.d = int(d)
         self.metric = metric
+        self.dtype = dtype
+        self._tdtype = torch.float32 if dtype == "f32" else torch.bfloat16
         self.device = _dev(device)
-        self._xb = torch.empty((0, self.d), dtype=torch.float32, device=self.device)
+        self._xb = torch.empty((0, self.d), dtype=self._tdtype, device=self.device)
+        self._store = self._xb          # backing storage of _xb (grown geometrically by add())
         self._cmax_t = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._cmax = None
         self._ws = None
@@ -101,28 +124,46 @@ class FlatIndex:
 
     def add(self, x):
         """Append rows (copied, ids = insertion order) -- ``IndexFlatIP.add``."""
-        x = _as_device_f32(x, self.device)
+        x = self._rows(x, "add")
+        n_old = self.ntotal
+        if n_old + x.shape[0] > self._store.shape[0]:          # amortised growth: no re-copy per add()
+            cap = max(n_old + x.shape[0], 2 * self._store.shape[0])
+            store = torch.empty((cap, self.d), dtype=self._tdtype, device=self.device)
+            store[:n_old] = self._xb
+            self._store = store
+        self._store[n_old:n_old + x.shape[0]] = x
+        self._xb = self._store[:n_old + x.shape[0]]
+        self._norm_max(x)
+
+    def _rows(self, x, what):
+        """Input rows as a contiguous device tensor of the index's element type."""
+        if isinstance(x, torch.Tensor) and x.dtype == torch.bfloat16 and self.dtype == "bf16":
+            x = x.to(self.device).contiguous()
+        else:
+            x = _as_device_f32(x, self.device)
+            if self.dtype == "bf16":
+                x = to_bf16(x)
         if x.dim() != 2 or x.shape[1] != self.d:
-            raise ValueError(f"add: expected [n, {self.d}], got {tuple(x.shape)}")
-        self._xb = x.clone() if self._xb.shape[0] == 0 else torch.cat([self._xb, x], dim=0)
-        if self.d % 4 == 0 and x.shape[0]:
-            rc = _lib.lib().sss_row_norm_max(x.data_ptr(), x.shape[0], self.d, self._cmax_t.data_ptr(),
-                                             _lib.stream_ptr(self.device))
+            raise ValueError(f"{what}: expected [n, {self.d}], got {tuple(x.shape)}")
+        return x
+
+    def _norm_max(self, x):
+        if x.shape[0] and self.d % (4 if self.dtype == "f32" else 8) == 0:
+            rc = _lib.lib().sss_row_norm_max(x.data_ptr(), x.shape[0], self.d, DTYPE_CODE[self.dtype],
+                                             self._cmax_t.data_ptr(), _lib.stream_ptr(self.device))
             _lib.check(rc, "sss_row_norm_max")
         self._cmax = None
 
     def adopt(self, xb: torch.Tensor, id_offset: int = 0):
-        """Use an existing CUDA float32 [n, d] tensor as the corpus without copying it."""
-        _lib.require_cuda(xb, "xb", torch.float32)
+        """Use an existing CUDA [n, d] tensor of the index's element type as the corpus without
+        copying it."""
+        _lib.require_cuda(xb, "xb", self._tdtype)
         if xb.dim() != 2 or xb.shape[1] != self.d:
             raise ValueError("adopt: wrong shape")
-        self._xb = xb
+        self._xb = self._store = xb
         self.id_offset = int(id_offset)
         self._cmax_t.zero_()
-        rc = _lib.lib().sss_row_norm_max(xb.data_ptr(), xb.shape[0], self.d, self._cmax_t.data_ptr(),
-                                         _lib.stream_ptr(self.device))
-        _lib.check(rc, "sss_row_norm_max")
-        self._cmax = None
+        self._norm_max(xb)
         return self
 
     def corpus_max_norm(self) -> float:
@@ -137,14 +178,14 @@ class FlatIndex:
         return self._ws
 
     def fused_ok(self, k: int) -> bool:
-        return self.metric == "ip" and self.d in FUSED_DIMS and 0 < k <= FUSED_MAX_K and self.ntotal > 0
+        return self.metric == "ip" and self.d in FUSED_DIMS[self.dtype] and 0 < k <= FUSED_MAX_K and self.ntotal > 0
 
     def search_fused(self, q: torch.Tensor, k: int, out=None):
         """Enqueue the fused MFMA scoring + top-k on the current stream; no host sync.
         Returns (D [nq,k] f32, I [nq,k] i64, status [nq] i32) CUDA tensors; rows with
         status != 0 must be re-run with ``search_exhaustive`` (``search`` does that)."""
         L = _lib.lib()
-        _lib.require_cuda(q, "q", torch.float32)
+        _lib.require_cuda(q, "q", self._tdtype)
         nq, n = q.shape[0], self.ntotal
         if out is None:
             D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
@@ -152,9 +193,9 @@ class FlatIndex:
             status = torch.empty((nq,), dtype=torch.int32, device=self.device)
         else:
             D, I, status = out
-        nbytes = L.sss_ip_topk_workspace_bytes(nq, n, self.d, k)
+        nbytes = L.sss_ip_topk_workspace_bytes(nq, n, self.d, k, DTYPE_CODE[self.dtype])
         ws = self._workspace(nbytes)
-        rc = L.sss_ip_topk(q.data_ptr(), nq, self._xb.data_ptr(), n, self.d, k, self.id_offset,
+        rc = L.sss_ip_topk(q.data_ptr(), nq, self._xb.data_ptr(), n, self.d, k, DTYPE_CODE[self.dtype], self.id_offset,
                            self.corpus_max_norm(), D.data_ptr(), I.data_ptr(), status.data_ptr(),
                            ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
         _lib.check(rc, "sss_ip_topk")
@@ -174,12 +215,14 @@ class FlatIndex:
             nbytes = L.sss_ip_topk_exhaustive_workspace_bytes(sel.numel(), n)
             ws = self._workspace(nbytes)
             rc = L.sss_ip_topk_exhaustive(q.data_ptr(), sel.data_ptr(), sel.numel(), self._xb.data_ptr(), n,
-                                          self.d, k, self.id_offset, metric, D.data_ptr(), I.data_ptr(),
+                                          self.d, k, DTYPE_CODE[self.dtype], self.id_offset, metric, D.data_ptr(), I.data_ptr(),
                                           ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
             _lib.check(rc, "sss_ip_topk_exhaustive")
 
     def search_device(self, q: torch.Tensor, k: int):
         """Exact search, CUDA tensors in and out (syncs once to read the status vector)."""
+        if q.dtype != self._tdtype:
+            q = self._rows(q, "search")
         nq = q.shape[0]
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
@@ -190,8 +233,8 @@ class FlatIndex:
             D.fill_(-3.4028234663852886e38 if self.metric == "ip" else 3.4028234663852886e38)
             I.fill_(-1)
             return D, I
-        if self.d % 4:
-            raise _lib.SssError("d must be a multiple of 4")
+        if self.d % (4 if self.dtype == "f32" else 8):
+            raise _lib.SssError("d must be a multiple of 4 (f32) / 8 (bf16)")
         if self.fused_ok(k):
             status = torch.empty((nq,), dtype=torch.int32, device=self.device)
             self.search_fused(q, k, (D, I, status))
@@ -207,9 +250,7 @@ class FlatIndex:
     def search(self, x, k: int):
         """``index.search(x, k) -> (D, I)``: numpy in -> numpy out (faiss), tensor in -> tensors."""
         is_np = isinstance(x, np.ndarray)
-        q = _as_device_f32(x, self.device)
-        if q.dim() != 2 or q.shape[1] != self.d:
-            raise ValueError(f"search: expected [nq, {self.d}], got {tuple(q.shape)}")
+        q = self._rows(x, "search")
         D, I = self.search_device(q, int(k))
         if is_np:
             return D.cpu().numpy(), I.cpu().numpy()

@@ -287,3 +287,85 @@ def test_config_c4_10m_rows(cuda):
     # oracle on 16 queries (1.6e8 pairs x 128)
     Dr, Ir = sr.search_exact(q[:16].cpu().numpy(), c.cpu().numpy(), k)
     assert np.array_equal(In[:16], Ir) and np.array_equal(Dn[:16], Dr)
+
+
+# ----------------------------------------------------------------------------------------------
+# bf16 index (BASELINE config C5): corpus and queries stored as bfloat16, scored on the bf16 MFMA
+# with float32 accumulation; the contract is the canonical float64 score of the ROUNDED vectors.
+def _bf16_round(x):
+    return torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+
+
+def test_f32_to_bf16_is_round_to_nearest_even(cuda):
+    from sessionsimilaritysearch_amd.index import to_bf16
+    rng = np.random.default_rng(40)
+    x = (rng.standard_normal(8 * 1000) * np.exp(rng.uniform(-20, 20, 8000))).astype(np.float32)
+    x[:8] = [0.0, -0.0, 1.0, 1.00390625, 1.01171875, np.inf, -np.inf, 3.3895314e38]   # ties + overflow to inf
+    got = to_bf16(torch.from_numpy(x).to(cuda)).cpu()
+    ref = torch.from_numpy(x).to(torch.bfloat16)
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("nq,n,d,k", [
+    (512, 50000, 256, 10),      # C5's row shape (d=256), small
+    (4096, 150000, 256, 10),    # C5's query batch
+    (64, 3000, 128, 10),
+    (100, 6000, 512, 10),
+    (40, 20000, 256, 100),      # reference K
+])
+def test_bf16_fused_matches_oracle_on_rounded_vectors(cuda, nq, n, d, k):
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(41 + nq + n)
+    q, c = _unit(rng, nq, d), _unit(rng, n, d)
+    idx = FlatIndex(d, "ip", cuda, dtype="bf16")
+    idx.add(c)
+    D, I = idx.search(q, k)
+    assert idx.last_fallback_queries <= nq // 50           # random data: (nearly) everything proven on the fused path
+    Dr, Ir = sr.search_exact(_bf16_round(q), _bf16_round(c), k)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_bf16_duplicates_and_exhaustive_path(cuda):
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(42)
+    base = _unit(rng, 40, 256)
+    c = np.ascontiguousarray(np.repeat(base, 30, axis=0)[rng.permutation(1200)])
+    q = _unit(rng, 16, 256)
+    idx = FlatIndex(256, "ip", cuda, dtype="bf16")
+    idx.add(c)
+    D, I = idx.search(q, 10)
+    Dr, Ir = sr.search_exact(_bf16_round(q), _bf16_round(c), 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    # a shape outside the fused kernel (d=64 bf16) goes through the exhaustive path
+    q2, c2 = _unit(rng, 5, 64), _unit(rng, 700, 64)
+    idx2 = FlatIndex(64, "ip", cuda, dtype="bf16")
+    idx2.add(c2)
+    D2, I2 = idx2.search(q2, 10)
+    Dr2, Ir2 = sr.search_exact(_bf16_round(q2), _bf16_round(c2), 10)
+    assert np.array_equal(I2, Ir2) and np.array_equal(D2, Dr2)
+
+
+def test_large_k_500_matches_oracle(cuda):
+    """sample_size = 500 neighbours (get_prediction_by_knn, test_amazon_filterd.py:61) on the fused path."""
+    rng = np.random.default_rng(43)
+    q, c = _unit(rng, 1024, 128), _unit(rng, 200000, 128)
+    idx = _index(c, cuda)
+    D, I = idx.search(q, 500)
+    Dr, Ir = sr.search_exact(q, c, 500)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    assert idx.last_fallback_queries <= 64
+
+
+def test_index_add_in_pieces_equals_single_add(cuda):
+    rng = np.random.default_rng(44)
+    c = _unit(rng, 5000, 128)
+    q = _unit(rng, 30, 128)
+    a = _index(c, cuda)
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    b = FlatIndex(128, "ip", cuda)
+    for lo in range(0, 5000, 777):
+        b.add(c[lo:lo + 777])
+    assert b.ntotal == 5000
+    Da, Ia = a.search(q, 10)
+    Db, Ib = b.search(q, 10)
+    assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)
