@@ -74,6 +74,7 @@ __global__ __launch_bounds__(512, 2) void k_scan(const ScanArgs A) {
     constexpr int TILE_BYTES = TR * RB;
     constexpr int LOADS_PER_WAVE = TR * CH / 64 / 8;  // LDS-DMA wave-instructions per wave per tile
     constexpr bool PRECOMP = RB <= 512;               // keep the DMA lane offsets in VGPRs (register budget)
+    constexpr int TAU_LDS = 2 * TILE_BYTES;           // [8 waves][32 queries][16 slots] u32 behind the two tile buffers
     static_assert(CH <= 64, "row longer than one LDS-DMA instruction");
     static_assert(LOADS_PER_WAVE >= 1 && LOADS_PER_WAVE < NU, "DMA pieces must fit the k loop");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -138,10 +139,35 @@ __global__ __launch_bounds__(512, 2) void k_scan(const ScanArgs A) {
         my_slot = A.slots + (size_t)q_ld * J + (unsigned)(2 * split + h) % (unsigned)J;
         my_half = A.slots + (size_t)q_ld * J + h * (J >> 1);
     }
-    // min over the query's J slots: each lane of the (h = 0, 1) pair reads half, 8 slots a step
+    // min over the query's J slots.  Synchronous form (bootstrap wait; J > 16): each lane of the
+    // (h = 0, 1) pair reads half, 8 slots a step, with agent-scope loads.
     auto tau_ord = [&]() -> unsigned {
         unsigned m = 0xFFFFFFFFu;
         for (int v = 0; v < (J >> 1); v += 8) m = min(m, min8_sc1(my_half + v));
+        return min(m, (unsigned)__shfl_xor((int)m, 32));
+    };
+    // Asynchronous form (J == 16, every iteration): the wave's 32 queries x 64 B of slots are
+    // fetched by two LDS-DMA instructions (agent scope) at the top of an iteration, land under the
+    // MFMAs, are retired by the iteration's vmcnt(0) and read back by their owner lanes: no
+    // stall, no registers held.
+    const unsigned tau_lds = (unsigned)(unsigned long)(lptr_c)smem + TAU_LDS + wave * 2048;
+    auto tau_fetch = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int qi = g * WG_QUERIES + wave * 32 + 16 * j + (lane >> 2);
+            if (qi > nq - 1) qi = nq - 1;
+            const unsigned off = (unsigned)qi * 64u + (unsigned)(lane & 3) * 16u;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(tau_lds + j * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %3 sc1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(off), "s"(dst), "s"(A.slots) : "memory");
+        }
+    };
+    auto tau_read = [&]() -> unsigned {
+        const u32x4* p = reinterpret_cast<const u32x4*>(smem + TAU_LDS + wave * 2048 + r * 64 + h * 32);
+        const u32x4 a = p[0], b = p[1];
+        const unsigned m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
         return min(m, (unsigned)__shfl_xor((int)m, 32));
     };
     auto set_tau = [&](unsigned m) {
@@ -161,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void k_scan(const ScanArgs A) {
             val = c == 2 ? v2 : c == 4 ? v4 : c == 8 ? v8 : v16;
             ok = (c == 2 ? i2 : c == 4 ? i4 : c == 8 ? i8 : i16) >= 0;
         }
-        if (ok && val > pub && q_glob < nq) {
+        if (ok && val > pub && val > tau && q_glob < nq) {     // at or below tau it cannot raise the minimum
             __hip_atomic_fetch_max(my_slot, f2ord(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pub = val;
         }
@@ -298,11 +324,16 @@ __global__ __launch_bounds__(512, 2) void k_scan(const ScanArgs A) {
     for (int i = 0; i < niter; ++i) {
         const int buf = i & 1;
         const bool pre = boot && i == 0;
+        const bool async_tau = use_tau && J == 16 && i > 0;
         if (use_tau && i > 0) {
-            // Threshold refresh: synchronous loads, staggered between the two waves of a SIMD
-            // (waves 4-7 one tile later) so the partner keeps the matrix pipe busy meanwhile.
-            const int ii = i - (wave >= 4 ? 1 : 0);
-            if (ii >= 2 && (ii <= 8 || (ii & (ii - 1)) == 0 || (ii & 15) == 0)) set_tau(tau_ord());
+            if (async_tau) {
+                tau_fetch();                                // lands under this iteration's MFMAs
+            } else {
+                // J > 16 (k > 116): synchronous loads, rarely, staggered between the two waves of a
+                // SIMD (waves 4-7 one tile later) so the partner keeps the matrix pipe busy meanwhile.
+                const int ii = i - (wave >= 4 ? 1 : 0);
+                if (ii >= 2 && (ii <= 8 || (ii & (ii - 1)) == 0 || (ii & 15) == 0)) set_tau(tau_ord());
+            }
             publish();      // completes under this tile's MFMAs
         }
         const int t_cur = tile_of(i);
@@ -330,6 +361,7 @@ __global__ __launch_bounds__(512, 2) void k_scan(const ScanArgs A) {
         }
         if (pre) publish();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile landed
+        if (async_tau) set_tau(tau_read());                // ... and so did its slots (own region: no barrier needed)
         __syncthreads();                                   // ... everyone's did, and this buffer is free
         if (pre) {
             // Wait (bounded) until every class of this wave's queries has published its bootstrap
@@ -416,7 +448,7 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
 
 template <int RB, int TR, int DT>
 static int launch_one(const ScanArgs& a, hipStream_t st) {
-    const size_t lds = 2 * (size_t)TR * RB;
+    const size_t lds = 2 * (size_t)TR * RB + 8 * 2048;       // two tile buffers + the threshold-slot staging
     static bool attr_done[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_done[dev]) {

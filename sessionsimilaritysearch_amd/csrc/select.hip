@@ -25,13 +25,24 @@ constexpr int SEL_MAX_K2 = 512;
 constexpr int SORT_THREADS = 256;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Wave-wide maximum of a u32 on the DPP network (no LDS round trips): row_shr 1/2/4/8 leave each
+// 16-lane row's maximum in its last lane, row_bcast15 / row_bcast31 carry it across rows, lane 63
+// holds the result.  bound_ctrl = true feeds 0 (the identity of umax) to lanes without a source.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));   // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));   // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));   // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));   // row_shr:8
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true));   // row_bcast:15 -> rows 1, 3
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true));   // row_bcast:31 -> rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit keys: maximum of the high words, then of the low words among the lanes that hold it.
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(v, o);
-        v = other > v ? other : v;
-    }
-    return v;
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned mh = wave_max_u32(hi);
+    const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+    return ((unsigned long long)mh << 32) | ml;
 }
 
 // Cross-lane hand-off through LDS inside ONE wave: the hardware runs a wave's LDS instructions in
@@ -204,9 +215,9 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
         }
         wave_sync();
     }
-    if (lane == 0) {
-        for (int kk = 0; kk < A.d; ++kk) { const double v = elem_to_f32(qrow, kk, A.dtype); qn2 += v * v; }
-    }
+    for (int kk = lane; kk < A.d; kk += 64) { const double v = elem_to_f32(qrow, kk, A.dtype); qn2 += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) qn2 += __shfl_xor(qn2, o);     // only feeds the error BOUND: order-free
     rank_and_write<64>(sel, resc, K2, k, A.id_offset, Dq, Iq, lane, s_nvalid, s_kth);
     wave_sync();
     const int nvalid = *s_nvalid;
