@@ -52,13 +52,16 @@ int sss_f32_to_bf16(const float* x, int64_t count, uint16_t* y, void* stream);
  * ordered by (score desc, id asc); missing results: I = -1, D = -FLT_MAX (faiss convention).
  * Scores are the canonical ones of DESIGN.md (float64 sequential dot of the stored elements,
  * rounded to float32).  status [nq] int32: 0 = proven exact, 1 = not proven (caller re-runs those
- * queries through sss_ip_topk_exhaustive).  corpus_max_norm = max row 2-norm of the corpus (for
+ * queries through sss_ip_topk_exhaustive); unproven_count (may be NULL): device int32 that is
+ * incremented once per unproven query (never reset here), so a caller can run many batches
+ * without a host sync and check once.  corpus_max_norm = max row 2-norm of the corpus (for
  * the error bound).  workspace: 256-byte aligned, sss_ip_topk_workspace_bytes() bytes (0 = shape
  * not supported by the fused path). */
 size_t sss_ip_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k, int dtype);
 int sss_ip_topk(const void* q, int64_t nq, const void* corpus, int64_t n, int d, int k, int dtype,
                 int64_t id_offset, float corpus_max_norm, float* D_out, int64_t* I_out,
-                int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+                int32_t* status, int32_t* unproven_count, void* workspace, size_t workspace_bytes,
+                void* stream);
 
 /* Exhaustive exact search for a (small) set of queries: qsel [nsel] int32 are the query rows of
  * q to process; results are written to rows qsel[i] of D_out / I_out.  Any n, any d % 4 == 0
@@ -133,6 +136,55 @@ int sss_segment_pool(const float* node, int64_t ld_node, const int32_t* pptr, co
                      const float* bcoarse, int64_t ld_b, const float* watt, float* out, int64_t ld_out,
                      void* stream);
 int sss_segment_ptr(const int64_t* batch, int64_t n, int64_t n_graphs, int32_t* ptr, void* stream);
+
+/* ---- (i) fused encoder path: 8 launches per forward (DESIGN.md "encoder").
+ *
+ * sss_linear_grouped: up to 4 node-linear problems  y = x w^T (+ bias)  in ONE launch (the product
+ * and query transforms of a HeteroGGNN layer -- model/gnn.py:54,58 --, the pooling's query_lin +
+ * product_lin, or node_emb_lin + coarse_rep_lin -- model/gnn.py:186-190).  k % 32 == 0, shared
+ * by all problems.  With ids != NULL the X rows are table[ids[r]] (NodeAsinEmbedding.forward,
+ * model/NodeEmbedding.py:137-138, fused into the transform; table row stride = k) and, when
+ * xcopy != NULL, are also written to xcopy[r * ld_xcopy] (slice 0 of the node buffer). */
+typedef struct {
+    const float* x; int64_t ldx;
+    const int64_t* ids; const float* table; float* xcopy; int64_t ld_xcopy;
+    const float* w; int64_t ldw; const float* bias;
+    float* y; int64_t ldy;
+    int64_t n; int32_t m; int32_t reserved;
+} sss_linear_problem;
+int sss_linear_grouped(const sss_linear_problem* problems, int n_problems, int k, void* stream);
+
+/* sss_hetero_layer_update: everything of one HeteroGGNN layer after the node transforms
+ * (model/gnn.py:67-73): per product node GATConv(query->product) aggregate + GatedGraphConv
+ * aggregate + GRUCell gates + HeteroConv sum + relu; per query node GATConv(product->query) +
+ * relu.  Column layout of the transforms (produced by sss_linear_grouped, weights fused by the
+ * caller):  yp [np, >= 7h+2]: xs_p | u_r u_z u_n | gh_r gh_z gh_n | alpha_src(pq) alpha_dst(qp)
+ *           yq [nq, >=  h+2]: xs_q | alpha_src(qp) alpha_dst(pq)
+ * where u = x (W_ggc W_ih^T) -- GRU input transform applied before the (linear) neighbour sum --
+ * and gh = W_hh x + b_hh.  CSR by target, int32, self-loop rewrite already applied.  h <= 256. */
+typedef struct {
+    const float* yp; int64_t ld_yp; const float* yq; int64_t ld_yq; int32_t h; int32_t d_x;
+    const int32_t* rowptr_qp; const int32_t* col_qp; const int32_t* rowptr_pp; const int32_t* col_pp;
+    const float* w_pp; const float* bias_qp; const float* b_ih;
+    const float* xin_p; int64_t ld_xin; float* out_p; int64_t ld_out_p; int64_t np;
+    const int32_t* rowptr_pq; const int32_t* col_pq; const float* bias_pq;
+    float* out_q; int64_t ld_out_q; int64_t nq;
+} sss_layer_args;
+int sss_hetero_layer_update(const sss_layer_args* args, void* stream);
+
+/* PositionalAttentionPooling.forward in two kernels around one sss_linear_grouped call
+ * (model/gnn.py:193-217): expand_mean writes node[e] = tanh([lin[src_row[e]] ; pos_emb[pos_id[e]]])
+ * and coarse[g] = mean over the graph's expanded rows; attention computes
+ * out[g] = mean_e(node[e] * (watt . sigmoid(a[e] + b[g]))) and, if normalize != 0, applies the
+ * reference normalize (util_amazon_filtered.py:28-31) to the row.  d = d_lin + p <= 256. */
+int sss_pool_expand_mean(const float* lin_p, const float* lin_q, int64_t ld_lin, const int32_t* src_row,
+                         const int32_t* pos_id, const int32_t* pptr, const int32_t* qptr, int64_t n_clicks,
+                         int64_t n_graphs, int d_lin, int p, const float* pos_emb, float* node,
+                         int64_t ld_node, float* coarse, int64_t ld_coarse, void* stream);
+int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64_t ld_a, const float* b,
+                       int64_t ld_b, const float* watt, const int32_t* pptr, const int32_t* qptr,
+                       int64_t n_clicks, int64_t n_graphs, int d, int normalize, float eps, float* out,
+                       int64_t ld_out, void* stream);
 
 #ifdef __cplusplus
 }

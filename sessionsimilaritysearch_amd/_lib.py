@@ -25,7 +25,7 @@ _SIGNATURES = {
     "sss_f32_to_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "sss_ip_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
     "sss_ip_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_float,
-                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sss_ip_topk_exhaustive_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sss_ip_topk_exhaustive": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                        c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
@@ -48,7 +48,30 @@ _SIGNATURES = {
     "sss_segment_pool": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                  c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "sss_segment_ptr": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "sss_linear_grouped": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "sss_hetero_layer_update": (c_int, [c_void_p, c_void_p]),
+    "sss_pool_expand_mean": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                     c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "sss_pool_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                   c_int64, c_int64, c_int, c_int, c_float, c_void_p, c_int64, c_void_p]),
 }
+
+
+class LinearProblem(ctypes.Structure):
+    """``sss_linear_problem`` of include/sss.h."""
+    _fields_ = [("x", c_void_p), ("ldx", c_int64), ("ids", c_void_p), ("table", c_void_p), ("xcopy", c_void_p),
+                ("ld_xcopy", c_int64), ("w", c_void_p), ("ldw", c_int64), ("bias", c_void_p), ("y", c_void_p),
+                ("ldy", c_int64), ("n", c_int64), ("m", c_int32), ("reserved", c_int32)]
+
+
+class LayerArgs(ctypes.Structure):
+    """``sss_layer_args`` of include/sss.h."""
+    _fields_ = [("yp", c_void_p), ("ld_yp", c_int64), ("yq", c_void_p), ("ld_yq", c_int64), ("h", c_int32), ("d_x", c_int32),
+                ("rowptr_qp", c_void_p), ("col_qp", c_void_p), ("rowptr_pp", c_void_p), ("col_pp", c_void_p),
+                ("w_pp", c_void_p), ("bias_qp", c_void_p), ("b_ih", c_void_p),
+                ("xin_p", c_void_p), ("ld_xin", c_int64), ("out_p", c_void_p), ("ld_out_p", c_int64), ("np", c_int64),
+                ("rowptr_pq", c_void_p), ("col_pq", c_void_p), ("bias_pq", c_void_p),
+                ("out_q", c_void_p), ("ld_out_q", c_int64), ("nq", c_int64)]
 
 
 def exported_symbols():

@@ -27,7 +27,7 @@ int check_launch(const char* what) {
 
 // implemented in the kernel translation units
 size_t ip_topk_workspace_bytes(long nq, long n, int d, int k, int dtype);
-int ip_topk(const void*, long, const void*, long, int, int, int, long, float, float*, long*, int*, void*,
+int ip_topk(const void*, long, const void*, long, int, int, int, long, float, float*, long*, int*, int*, void*,
             size_t, hipStream_t);
 int topk_merge(const float*, long, const long*, long, int, long, int, float*, long*, hipStream_t);
 int profile_enable(int);
@@ -51,6 +51,24 @@ int segment_pool(const float*, long, const int*, const int*, long, long, int, co
                  const float*, float*, long, hipStream_t);
 int segment_ptr(const long*, long, long, int*, hipStream_t);
 
+struct LinProb {
+    const float* x; long ldx; const long* ids; const float* table; float* xcopy; long ld_xcopy;
+    const float* w; long ldw; const float* bias; float* y; long ldy; long n; int m; int tiles_m, tile_begin;
+};
+struct LinBatch { LinProb p[4]; int nprob; int K; };
+int linear_grouped(LinBatch&, hipStream_t);
+struct LayerArgs {
+    const float* Yp; long ldyp; const float* Yq; long ldyq; int h;
+    const int* rowptr_qp; const int* col_qp; const int* rowptr_pp; const int* col_pp; const float* w_pp;
+    const float* bias_qp; const float* b_ih; const float* xin_p; long ld_xin; int d_x; float* out_p; long ld_outp; long Np;
+    const int* rowptr_pq; const int* col_pq; const float* bias_pq; float* out_q; long ld_outq; long Nq;
+};
+int layer_update(const LayerArgs&, hipStream_t);
+int pool_expand_mean(const float*, const float*, long, const int*, const int*, const int*, const int*, long, long, int, int,
+                     const float*, float*, long, float*, long, hipStream_t);
+int pool_attention(const float*, long, const float*, long, const float*, long, const float*, const int*, const int*, long, long,
+                   int, int, float, float*, long, hipStream_t);
+
 }  // namespace sss
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -73,10 +91,10 @@ size_t sss_ip_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k, int dtyp
     return sss::ip_topk_workspace_bytes(nq, n, d, k, dtype);
 }
 int sss_ip_topk(const void* q, int64_t nq, const void* corpus, int64_t n, int d, int k, int dtype, int64_t id_offset,
-                float corpus_max_norm, float* D_out, int64_t* I_out, int32_t* status, void* workspace,
-                size_t workspace_bytes, void* stream) {
+                float corpus_max_norm, float* D_out, int64_t* I_out, int32_t* status, int32_t* unproven_count,
+                void* workspace, size_t workspace_bytes, void* stream) {
     return sss::ip_topk(q, nq, corpus, n, d, k, dtype, id_offset, corpus_max_norm, D_out,
-                        reinterpret_cast<long*>(I_out), status, workspace, workspace_bytes, ST(stream));
+                        reinterpret_cast<long*>(I_out), status, unproven_count, workspace, workspace_bytes, ST(stream));
 }
 size_t sss_ip_topk_exhaustive_workspace_bytes(int64_t nsel, int64_t n) {
     return sss::ip_topk_exhaustive_workspace_bytes(nsel, n);
@@ -129,6 +147,42 @@ int sss_segment_pool(const float* node, int64_t ld_node, const int32_t* pptr, co
                      const float* watt, float* out, int64_t ld_out, void* stream) {
     return sss::segment_pool(node, ld_node, pptr, qptr, n_clicks, n_graphs, d, a, ld_a, bcoarse, ld_b, watt, out,
                              ld_out, ST(stream));
+}
+int sss_linear_grouped(const sss_linear_problem* problems, int n_problems, int k, void* stream) {
+    if (!problems || n_problems < 1 || n_problems > 4) { sss::set_error("linear_grouped: 1..4 problems"); return SSS_EINVAL; }
+    sss::LinBatch b;
+    b.nprob = n_problems; b.K = k;
+    for (int i = 0; i < n_problems; ++i) {
+        const sss_linear_problem& s = problems[i];
+        sss::LinProb& p = b.p[i];
+        p.x = s.x; p.ldx = s.ldx; p.ids = reinterpret_cast<const long*>(s.ids); p.table = s.table; p.xcopy = s.xcopy;
+        p.ld_xcopy = s.ld_xcopy; p.w = s.w; p.ldw = s.ldw; p.bias = s.bias; p.y = s.y; p.ldy = s.ldy; p.n = s.n; p.m = s.m;
+        p.tiles_m = 0; p.tile_begin = 0;
+    }
+    return sss::linear_grouped(b, ST(stream));
+}
+int sss_hetero_layer_update(const sss_layer_args* a, void* stream) {
+    if (!a) { sss::set_error("hetero_layer_update: null args"); return SSS_EINVAL; }
+    sss::LayerArgs l;
+    l.Yp = a->yp; l.ldyp = a->ld_yp; l.Yq = a->yq; l.ldyq = a->ld_yq; l.h = a->h; l.d_x = a->d_x;
+    l.rowptr_qp = a->rowptr_qp; l.col_qp = a->col_qp; l.rowptr_pp = a->rowptr_pp; l.col_pp = a->col_pp; l.w_pp = a->w_pp;
+    l.bias_qp = a->bias_qp; l.b_ih = a->b_ih; l.xin_p = a->xin_p; l.ld_xin = a->ld_xin; l.out_p = a->out_p;
+    l.ld_outp = a->ld_out_p; l.Np = a->np; l.rowptr_pq = a->rowptr_pq; l.col_pq = a->col_pq; l.bias_pq = a->bias_pq;
+    l.out_q = a->out_q; l.ld_outq = a->ld_out_q; l.Nq = a->nq;
+    return sss::layer_update(l, ST(stream));
+}
+int sss_pool_expand_mean(const float* lin_p, const float* lin_q, int64_t ld_lin, const int32_t* src_row,
+                         const int32_t* pos_id, const int32_t* pptr, const int32_t* qptr, int64_t n_clicks,
+                         int64_t n_graphs, int d_lin, int p, const float* pos_emb, float* node, int64_t ld_node,
+                         float* coarse, int64_t ld_coarse, void* stream) {
+    return sss::pool_expand_mean(lin_p, lin_q, ld_lin, src_row, pos_id, pptr, qptr, n_clicks, n_graphs, d_lin, p, pos_emb,
+                                 node, ld_node, coarse, ld_coarse, ST(stream));
+}
+int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64_t ld_a, const float* b, int64_t ld_b,
+                       const float* watt, const int32_t* pptr, const int32_t* qptr, int64_t n_clicks, int64_t n_graphs,
+                       int d, int normalize, float eps, float* out, int64_t ld_out, void* stream) {
+    return sss::pool_attention(node, ld_node, a, ld_a, b, ld_b, watt, pptr, qptr, n_clicks, n_graphs, d, normalize, eps, out,
+                               ld_out, ST(stream));
 }
 int sss_segment_ptr(const int64_t* batch, int64_t n, int64_t n_graphs, int32_t* ptr, void* stream) {
     return sss::segment_ptr(reinterpret_cast<const long*>(batch), n, n_graphs, ptr, ST(stream));

@@ -437,3 +437,371 @@ int segment_ptr(const long* batch, long n, long n_graphs, int* ptr, hipStream_t 
 }
 
 }  // namespace sss
+
+// =============================================================================================
+// Fused encoder path (8 launches per forward; DESIGN.md "encoder"):
+//   k_linear_grouped   one launch for up to 4 node-linear problems (products + queries of a layer,
+//                      or the pooling's lin_p + lin_q, or node_lin + coarse_lin); layer 0 reads its
+//                      X rows straight from the feature tables (NodeAsinEmbedding gather fused in)
+//   k_layer_update     per target node: GAT segment-softmax aggregate + GatedGraphConv aggregate +
+//                      GRU gates + HeteroConv sum + relu, everything in registers
+//   k_pool_expand_mean tanh([lin ; pos]) rows + per-graph mean
+//   k_pool_attention   attention-weighted per-graph mean (+ optional L2 normalise)
+namespace sss {
+
+struct LinProb {
+    const float* x; long ldx;          // X rows (ignored when ids != nullptr)
+    const long* ids; const float* table;   // gather mode: X[r] = table[ids[r]] (table row stride = K)
+    float* xcopy; long ld_xcopy;       // gather mode: also written here (slice 0 of the node buffer); may be null
+    const float* w; long ldw; const float* bias;
+    float* y; long ldy;
+    long n; int m;
+    int tiles_m, tile_begin;           // filled by the launcher
+};
+struct LinBatch { LinProb p[4]; int nprob; int K; };
+
+template <int KC>
+__global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
+    constexpr int CPR = KC / 4;
+    constexpr int NLD = LT * CPR / 256;
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    float* lx = lds_raw;
+    float* lw = lds_raw + LT * 128;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < B.nprob && (int)blockIdx.x >= B.p[i].tile_begin) pi = i;
+    // copy the chosen problem's fields through scalar selects (no runtime-indexed struct access)
+    const float* X = B.p[0].x; long ldx = B.p[0].ldx; const long* ids = B.p[0].ids; const float* table = B.p[0].table;
+    float* xcopy = B.p[0].xcopy; long ldc = B.p[0].ld_xcopy; const float* W = B.p[0].w; long ldw = B.p[0].ldw;
+    const float* bias = B.p[0].bias; float* Y = B.p[0].y; long ldy = B.p[0].ldy; long N = B.p[0].n; int M = B.p[0].m;
+    int tiles_m = B.p[0].tiles_m, tile_begin = B.p[0].tile_begin;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (pi == i) {
+            X = B.p[i].x; ldx = B.p[i].ldx; ids = B.p[i].ids; table = B.p[i].table; xcopy = B.p[i].xcopy; ldc = B.p[i].ld_xcopy;
+            W = B.p[i].w; ldw = B.p[i].ldw; bias = B.p[i].bias; Y = B.p[i].y; ldy = B.p[i].ldy; N = B.p[i].n; M = B.p[i].m;
+            tiles_m = B.p[i].tiles_m; tile_begin = B.p[i].tile_begin;
+        }
+    const int K = B.K;
+    const int t = (int)blockIdx.x - tile_begin;
+    const long row0 = (long)(t / tiles_m) * LT;
+    const int col0 = (t % tiles_m) * LT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int xr = wr * 32 + r, wrow = wc * 32 + r;
+
+    f32x16 acc = {0};
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        f32x4 sx[NLD], sw[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = tid + 256 * i;
+            const int tr = p / CPR, c = p % CPR;
+            long gr = row0 + tr; if (gr > N - 1) gr = N - 1;
+            int gw = col0 + tr; if (gw > M - 1) gw = M - 1;
+            const float* xrow = ids ? table + ids[gr] * (long)K : X + gr * ldx;
+            sx[i] = *reinterpret_cast<const f32x4*>(xrow + k0 + c * 4);
+            sw[i] = *reinterpret_cast<const f32x4*>(W + (long)gw * ldw + k0 + c * 4);
+            if (ids && xcopy && col0 == 0 && row0 + tr < N)          // the gathered rows = slice 0 of the node buffer
+                *reinterpret_cast<f32x4*>(xcopy + gr * ldc + k0 + c * 4) = sx[i];
+        }
+        if (k0 > 0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int p = tid + 256 * i;
+            const int tr = p / CPR, c = p % CPR;
+            const int cs = c ^ (tr & 15);
+            *reinterpret_cast<f32x4*>(lx + (tr * 32 + cs) * 4) = sx[i];
+            *reinterpret_cast<f32x4*>(lw + (tr * 32 + cs) * 4) = sw[i];
+        }
+        __syncthreads();
+        float4 a = *reinterpret_cast<const float4*>(lx + (xr * 32 + (h ^ (xr & 15))) * 4);
+        float4 b = *reinterpret_cast<const float4*>(lw + (wrow * 32 + (h ^ (wrow & 15))) * 4);
+#pragma unroll
+        for (int u = 0; u < KC / 8; ++u) {
+            float4 na = a, nb = b;
+            if (u + 1 < KC / 8) {
+                na = *reinterpret_cast<const float4*>(lx + (xr * 32 + ((2 * u + 2 + h) ^ (xr & 15))) * 4);
+                nb = *reinterpret_cast<const float4*>(lw + (wrow * 32 + ((2 * u + 2 + h) ^ (wrow & 15))) * 4);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            a = na; b = nb;
+        }
+    }
+    const int col = col0 + wc * 32 + r;
+    if (col < M) {
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const long row = row0 + wr * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+            if (row < N) Y[row * ldy + col] = acc[j] + bv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One LPR-lane group per TARGET node (LPR = h / 4: a lane owns one float4 column of the h-wide
+// row).  Targets [0, Np) are products, [Np, Np + Nq) queries.
+//   product i:  t1 = GAT(query -> product)  (Appendix A.2: leaky_relu(0.2), per-target softmax,
+//                    + 1e-16 in the denominator, + bias)
+//               gi = sum_{j -> i} w_ij u[j] + b_ih   with u = x (W_g W_ih^T): the GatedGraphConv
+//                    message transform and the GRU input transform applied BEFORE the (linear)
+//                    aggregation, so no second GEMM is needed (Appendix A.3)
+//               out = relu(t1 + (1 - z) n + z x),  r, z, n = GRU gates of (gi, gh = W_hh x + b_hh)
+//   query i:    out = relu(GAT(product -> query))
+// Column layout of the node-linear outputs (written by k_linear_grouped, see encoder.py):
+//   Yp [Np, 7h+32]: xs_p | u_r u_z u_n | gh_r gh_z gh_n | a_src(pq) a_dst(qp)
+//   Yq [Nq,  h+32]: xs_q | a_src(qp) a_dst(pq)
+struct LayerArgs {
+    const float* Yp; long ldyp; const float* Yq; long ldyq; int h;
+    const int* rowptr_qp; const int* col_qp; const int* rowptr_pp; const int* col_pp; const float* w_pp;
+    const float* bias_qp; const float* b_ih; const float* xin_p; long ld_xin; int d_x; float* out_p; long ld_outp; long Np;
+    const int* rowptr_pq; const int* col_pq; const float* bias_pq; float* out_q; long ld_outq; long Nq;
+};
+
+__device__ __forceinline__ float4 f4_fma(float w, float4 x, float4 a) {
+    a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;
+    return a;
+}
+__device__ __forceinline__ float leaky02(float v) { return v > 0.f ? v : 0.2f * v; }
+
+// softmax-weighted sum over the incoming edges of one target: returns sum_e softmax_e * xs[col[e]][c4] + bias
+__device__ __forceinline__ float4 gat_row(const float* xs, long ld, const float* a_src_col, float ad, const int* col,
+                                          int e0, int e1, int c4, const float* bias) {
+    float mx = -INFINITY;
+    for (int e = e0; e < e1; ++e) mx = fmaxf(mx, leaky02(a_src_col[(long)col[e] * ld] + ad));
+    float den = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = e0; e < e1; ++e) {
+        const long j = col[e];
+        const float ex = expf(leaky02(a_src_col[j * ld] + ad) - mx);
+        den += ex;
+        acc = f4_fma(ex, *reinterpret_cast<const float4*>(xs + j * ld + c4), acc);
+    }
+    const float inv = 1.f / (den + 1e-16f);
+    const float4 b = *reinterpret_cast<const float4*>(bias + c4);
+    return make_float4(acc.x * inv + b.x, acc.y * inv + b.y, acc.z * inv + b.z, acc.w * inv + b.w);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_layer_update(const LayerArgs A) {
+    const int sub = threadIdx.x % LPR;
+    const long per_block = 256 / LPR;
+    const long t = (long)blockIdx.x * per_block + threadIdx.x / LPR;
+    const int h = A.h, c4 = sub * 4;
+    if (c4 >= h || t >= A.Np + A.Nq) return;
+    if (t >= A.Np) {                                            // ---- query target
+        const long i = t - A.Np;
+        const float ad = A.Yq[i * A.ldyq + h + 1];
+        float4 o = gat_row(A.Yp, A.ldyp, A.Yp + 7 * h, ad, A.col_pq, A.rowptr_pq[i], A.rowptr_pq[i + 1], c4, A.bias_pq);
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        *reinterpret_cast<float4*>(A.out_q + i * A.ld_outq + c4) = o;
+        return;
+    }
+    const long i = t;                                           // ---- product target
+    const float* yi = A.Yp + i * A.ldyp;
+    const float4 t1 = gat_row(A.Yq, A.ldyq, A.Yq + h, yi[7 * h + 1], A.col_qp, A.rowptr_qp[i], A.rowptr_qp[i + 1], c4, A.bias_qp);
+    float4 gr = *reinterpret_cast<const float4*>(A.b_ih + c4);
+    float4 gz = *reinterpret_cast<const float4*>(A.b_ih + h + c4);
+    float4 gn = *reinterpret_cast<const float4*>(A.b_ih + 2 * h + c4);
+    for (int e = A.rowptr_pp[i]; e < A.rowptr_pp[i + 1]; ++e) {
+        const float* uj = A.Yp + (long)A.col_pp[e] * A.ldyp + h + c4;
+        const float w = A.w_pp ? A.w_pp[e] : 1.f;
+        gr = f4_fma(w, *reinterpret_cast<const float4*>(uj), gr);
+        gz = f4_fma(w, *reinterpret_cast<const float4*>(uj + h), gz);
+        gn = f4_fma(w, *reinterpret_cast<const float4*>(uj + 2 * h), gn);
+    }
+    const float4 hr = *reinterpret_cast<const float4*>(yi + 4 * h + c4);
+    const float4 hz = *reinterpret_cast<const float4*>(yi + 5 * h + c4);
+    const float4 hn = *reinterpret_cast<const float4*>(yi + 6 * h + c4);
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xi = A.xin_p + i * A.ld_xin;
+    if (c4 + 3 < A.d_x) xv = *reinterpret_cast<const float4*>(xi + c4);
+    else {
+        if (c4 + 0 < A.d_x) xv.x = xi[c4 + 0];
+        if (c4 + 1 < A.d_x) xv.y = xi[c4 + 1];
+        if (c4 + 2 < A.d_x) xv.z = xi[c4 + 2];
+    }
+    float4 o;
+#define SSS_GRU1(f)                                                        \
+    {                                                                      \
+        const float rr = sigmoidf_(gr.f + hr.f);                           \
+        const float zz = sigmoidf_(gz.f + hz.f);                           \
+        const float nn = tanhf(gn.f + rr * hn.f);                          \
+        o.f = fmaxf(t1.f + (1.f - zz) * nn + zz * xv.f, 0.f);              \
+    }
+    SSS_GRU1(x) SSS_GRU1(y) SSS_GRU1(z) SSS_GRU1(w)
+#undef SSS_GRU1
+    *reinterpret_cast<float4*>(A.out_p + i * A.ld_outp + c4) = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// PositionalAttentionPooling, first half (model/gnn.py:195-211): one LPR-lane group per graph g
+// walks its expanded rows (product clicks [pptr[g], pptr[g+1]), then query rows
+// n_clicks + [qptr[g], qptr[g+1])), writes node[e] = tanh([lin[src_row[e]] ; pos_emb[pos_id[e]]])
+// and the graph mean coarse[g] (global_mean_pool).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_pool_expand_mean(const float* __restrict__ lin_p, const float* __restrict__ lin_q,
+                                                          long ld_lin, const int* __restrict__ src_row,
+                                                          const int* __restrict__ pos_id, const int* __restrict__ pptr,
+                                                          const int* __restrict__ qptr, long n_clicks, long n_graphs,
+                                                          int Dl, int P, const float* __restrict__ pos_emb,
+                                                          float* __restrict__ node, long ld_node,
+                                                          float* __restrict__ coarse, long ld_coarse) {
+    const int sub = threadIdx.x % LPR;
+    const long g = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    const int D = Dl + P, c4 = sub * 4;
+    if (g >= n_graphs || c4 >= D) return;
+    const int p0 = pptr[g], p1 = pptr[g + 1], q0 = qptr[g], q1 = qptr[g + 1];
+    const int cnt = (p1 - p0) + (q1 - q0);
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < cnt; ++t) {
+        const bool is_p = t < (p1 - p0);
+        const long e = is_p ? (long)(p0 + t) : n_clicks + (long)(q0 + t - (p1 - p0));
+        const float* lin = (is_p ? lin_p : lin_q) + (long)src_row[e] * ld_lin;
+        const float* pe = pos_emb + (long)pos_id[e] * P;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c4 + u;
+            v[u] = tanhf(c < Dl ? lin[c] : pe[c - Dl]);
+        }
+        const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(node + e * ld_node + c4) = o;
+        m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+    }
+    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    *reinterpret_cast<float4*>(coarse + g * ld_coarse + c4) = make_float4(m.x * inv, m.y * inv, m.z * inv, m.w * inv);
+}
+
+// Second half (model/gnn.py:212-217): att_e = watt . sigmoid(a[e] + b[g]);  out[g] = mean_e(node[e] * att_e);
+// normalize != 0 additionally applies the reference's `normalize` (util_amazon_filtered.py:28-31,
+// x / sqrt(max(sum x^2, eps))) to the row, saving a pass over the session vectors.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_pool_attention(const float* __restrict__ node, long ld_node,
+                                                        const float* __restrict__ Aa, long ld_a,
+                                                        const float* __restrict__ Bc, long ld_b,
+                                                        const float* __restrict__ watt, const int* __restrict__ pptr,
+                                                        const int* __restrict__ qptr, long n_clicks, long n_graphs,
+                                                        int D, int normalize, float eps, float* __restrict__ out,
+                                                        long ld_out) {
+    const int sub = threadIdx.x % LPR;
+    const long g = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    const int c4 = sub * 4;
+    const bool live = g < n_graphs && c4 < D;                   // dead lanes still take part in the shuffles
+    int p0 = 0, p1 = 0, q0 = 0, q1 = 0;
+    if (g < n_graphs) { p0 = pptr[g]; p1 = pptr[g + 1]; q0 = qptr[g]; q1 = qptr[g + 1]; }
+    const int cnt = (p1 - p0) + (q1 - q0);
+    float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = w4, acc = w4;
+    if (live) { w4 = *reinterpret_cast<const float4*>(watt + c4); b4 = *reinterpret_cast<const float4*>(Bc + g * ld_b + c4); }
+    for (int t = 0; t < cnt; ++t) {
+        const long e = t < (p1 - p0) ? (long)(p0 + t) : n_clicks + (long)(q0 + t - (p1 - p0));
+        float part = 0.f;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            const float4 a = *reinterpret_cast<const float4*>(Aa + e * ld_a + c4);
+            v = *reinterpret_cast<const float4*>(node + e * ld_node + c4);
+            part = w4.x * sigmoidf_(a.x + b4.x) + w4.y * sigmoidf_(a.y + b4.y) + w4.z * sigmoidf_(a.z + b4.z) +
+                   w4.w * sigmoidf_(a.w + b4.w);
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        acc = f4_fma(part, v, acc);
+    }
+    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    if (normalize) {
+        float ss = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const float den = sqrtf(fmaxf(ss, eps));
+        acc.x /= den; acc.y /= den; acc.z /= den; acc.w /= den;
+    }
+    if (live) *reinterpret_cast<float4*>(out + g * ld_out + c4) = acc;
+}
+
+// ------------------------------------------------------------------------------ host launchers
+int linear_grouped(LinBatch& b, hipStream_t st) {
+    if (b.nprob < 1 || b.nprob > 4 || b.K <= 0 || b.K % 32) { set_error("linear_grouped: 1..4 problems, K %% 32 == 0"); return SSS_EINVAL; }
+    int total = 0;
+    for (int i = 0; i < b.nprob; ++i) {
+        LinProb& p = b.p[i];
+        if (p.n < 0 || p.m <= 0 || p.ldw % 4 || p.ldw < b.K || p.ldy < p.m || (!p.ids && (p.ldx % 4 || p.ldx < b.K)) ||
+            (p.ids && (!p.table || (p.xcopy && (p.ld_xcopy % 4 || p.ld_xcopy < b.K))))) {
+            set_error("linear_grouped: problem %d has bad strides / shapes", i);
+            return SSS_EINVAL;
+        }
+        p.tiles_m = (p.m + LT - 1) / LT;
+        p.tile_begin = total;
+        total += (int)((p.n + LT - 1) / LT) * p.tiles_m;
+    }
+    for (int i = b.nprob; i < 4; ++i) { b.p[i] = b.p[0]; b.p[i].tile_begin = 0x7fffffff; }
+    if (total == 0) return SSS_OK;
+    const int lds = 2 * LT * 128 * 4;
+    static bool attr_done[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev); if (dev < 0 || dev >= 64) dev = 0;
+    if (!attr_done[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_grouped<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_grouped<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_grouped<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done[dev] = true;
+    }
+    if (b.K % 128 == 0) hipLaunchKernelGGL(k_linear_grouped<128>, dim3((unsigned)total), dim3(256), lds, st, b);
+    else if (b.K % 64 == 0) hipLaunchKernelGGL(k_linear_grouped<64>, dim3((unsigned)total), dim3(256), lds, st, b);
+    else hipLaunchKernelGGL(k_linear_grouped<32>, dim3((unsigned)total), dim3(256), lds, st, b);
+    return check_launch("k_linear_grouped");
+}
+
+int layer_update(const LayerArgs& a, hipStream_t st) {
+    if (a.h <= 0 || a.h % 4 || a.h > 256 || a.Np < 0 || a.Nq < 0 || a.d_x > a.h || a.ldyp % 4 || a.ldyq % 4 || a.ld_outp % 4 ||
+        a.ld_outq % 4 || (a.d_x >= 4 && a.ld_xin % 4) || a.ldyp < 7 * a.h + 2 || a.ldyq < a.h + 2) {
+        set_error("layer_update: need h %% 4 == 0, h <= 256, d_x <= h, 16-byte aligned row strides, ldyp >= 7h+2, ldyq >= h+2");
+        return SSS_EINVAL;
+    }
+    const long total = a.Np + a.Nq;
+    if (total == 0) return SSS_OK;
+    const int lpr = lanes_for(a.h);
+    const long per = 256 / lpr;
+    SSS_LPR_SWITCH(lpr, hipLaunchKernelGGL(k_layer_update<L>, dim3((unsigned)((total + per - 1) / per)), dim3(256), 0, st, a));
+    return check_launch("k_layer_update");
+}
+
+int pool_expand_mean(const float* lin_p, const float* lin_q, long ld_lin, const int* src_row, const int* pos_id,
+                     const int* pptr, const int* qptr, long n_clicks, long n_graphs, int Dl, int P, const float* pos_emb,
+                     float* node, long ld_node, float* coarse, long ld_coarse, hipStream_t st) {
+    const int D = Dl + P;
+    if (n_graphs < 0 || Dl <= 0 || P < 0 || D % 4 || D > 256 || ld_node % 4 || ld_node < D || ld_coarse % 4 || ld_coarse < D) {
+        set_error("pool_expand_mean: need (Dl + P) %% 4 == 0, <= 256, 16-byte aligned row strides");
+        return SSS_EINVAL;
+    }
+    if (n_graphs == 0) return SSS_OK;
+    const int lpr = lanes_for(D);
+    const long per = 256 / lpr;
+    SSS_LPR_SWITCH(lpr, hipLaunchKernelGGL(k_pool_expand_mean<L>, dim3((unsigned)((n_graphs + per - 1) / per)), dim3(256), 0, st,
+                                           lin_p, lin_q, ld_lin, src_row, pos_id, pptr, qptr, n_clicks, n_graphs, Dl, P, pos_emb,
+                                           node, ld_node, coarse, ld_coarse));
+    return check_launch("k_pool_expand_mean");
+}
+
+int pool_attention(const float* node, long ld_node, const float* Aa, long ld_a, const float* Bc, long ld_b, const float* watt,
+                   const int* pptr, const int* qptr, long n_clicks, long n_graphs, int D, int normalize, float eps, float* out,
+                   long ld_out, hipStream_t st) {
+    if (n_graphs < 0 || D <= 0 || D % 4 || D > 256 || ld_node % 4 || ld_a % 4 || ld_b % 4 || ld_out % 4 || ld_out < D) {
+        set_error("pool_attention: need D %% 4 == 0, D <= 256, 16-byte aligned row strides");
+        return SSS_EINVAL;
+    }
+    if (n_graphs == 0) return SSS_OK;
+    const int lpr = lanes_for(D);
+    const long per = 256 / lpr;
+    SSS_LPR_SWITCH(lpr, hipLaunchKernelGGL(k_pool_attention<L>, dim3((unsigned)((n_graphs + per - 1) / per)), dim3(256), 0, st, node,
+                                           ld_node, Aa, ld_a, Bc, ld_b, watt, pptr, qptr, n_clicks, n_graphs, D, normalize, eps, out,
+                                           ld_out));
+    return check_launch("k_pool_attention");
+}
+
+}  // namespace sss

@@ -56,8 +56,8 @@ size_t ip_topk_workspace_bytes(long nq, long n, int d, int k, int dtype) {
 }
 
 int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dtype, long id_offset,
-            float corpus_max_norm, float* D_out, long* I_out, int* status, void* ws, size_t ws_bytes,
-            hipStream_t st) {
+            float corpus_max_norm, float* D_out, long* I_out, int* status, int* unproven_count, void* ws,
+            size_t ws_bytes, hipStream_t st) {
     if (nq <= 0 || n <= 0 || k <= 0) { set_error("ip_topk: nq, n, k must be positive"); return SSS_EINVAL; }
     if (!fused_shape_ok(d, dtype)) {
         set_error("ip_topk: need dtype 0 (f32, d in {64,128,256}) or 1 (bf16, d in {128,256,512}); got dtype %d d %d", dtype, d);
@@ -90,7 +90,7 @@ int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dty
     s.Q = q; s.C = c; s.nq = (int)nq; s.d = d; s.dtype = dtype; s.k = k; s.K2 = p.K2; s.J = p.J; s.cap = p.cap;
     s.cand = a.cand; s.cnt = a.cnt; s.maxlast = a.maxlast; s.slots = a.slots;
     s.id_offset = id_offset; s.corpus_max_norm = corpus_max_norm;
-    s.D_out = D_out; s.I_out = I_out; s.status = status;
+    s.D_out = D_out; s.I_out = I_out; s.status = status; s.unproven_count = unproven_count;
     return launch_select(s, st);
 }
 

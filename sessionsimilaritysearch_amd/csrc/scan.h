@@ -53,6 +53,7 @@ struct SelectArgs {
     float* D_out;
     long* I_out;
     int* status;
+    int* unproven_count;        // optional device counter: += 1 per query left unproven
 };
 
 int launch_select(const SelectArgs& a, hipStream_t st);

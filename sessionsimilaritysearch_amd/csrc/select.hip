@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     long* Iq = A.I_out + (size_t)q * k;
     const int M = (int)A.cnt[q];
     if (M > FS_CAP) {                                             // adversarial input: let the exhaustive path decide
-        if (lane == 0) A.status[q] = 1;
+        if (lane == 0) { A.status[q] = 1; if (A.unproven_count) atomicAdd(A.unproven_count, 1); }
         return;
     }
     // ---- stage keys and the query row; per-lane best of keys lane, lane+64, ...
@@ -228,7 +228,9 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     const unsigned tau_o = A.J > 0 ? final_tau_ord(A.slots + (size_t)q * A.J, A.J, lane) : 0u;
     if (lane == 0) {
         const double B = err_bound(A.d, A.dtype, sqrt(qn2), (double)A.corpus_max_norm);
-        A.status[q] = decide_status(sel[K2 - 1], A.maxlast[q], tau_o, A.J, nvalid, k, *s_kth, B);
+        const int st = decide_status(sel[K2 - 1], A.maxlast[q], tau_o, A.J, nvalid, k, *s_kth, B);
+        A.status[q] = st;
+        if (st && A.unproven_count) atomicAdd(A.unproven_count, 1);
     }
 }
 
@@ -300,7 +302,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
             double qq = 0.0;
             for (int w = 0; w < SORT_THREADS / 64; ++w) qq += s_q2[w];
             const double B = err_bound(A.d, A.dtype, sqrt(qq), (double)A.corpus_max_norm);
-            A.status[q] = decide_status(keys[K2 - 1], A.maxlast[q], tau_o, A.J, nvalid, k, s_kth, B);
+            const int st = decide_status(keys[K2 - 1], A.maxlast[q], tau_o, A.J, nvalid, k, s_kth, B);
+            A.status[q] = st;
+            if (st && A.unproven_count) atomicAdd(A.unproven_count, 1);
         }
     }
 }

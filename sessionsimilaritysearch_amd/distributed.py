@@ -30,9 +30,11 @@ class HipEngine:
 
     def __init__(self, index):
         self.index = index
+        # running count of queries the fused path could not prove exact (device side, no sync)
+        self.unproven = torch.zeros(1, dtype=torch.int32, device=index.device)
 
     def local_search(self, q, k, D, I, status):
-        self.index.search_fused(q, k, (D, I, status))
+        self.index.search_fused(q, k, (D, I, status), self.unproven)
 
     def fix_unproven(self, q, k, D, I, status):
         bad = torch.nonzero(status).flatten()

@@ -14,6 +14,7 @@ Out of scope, by design: the reference's BERT/ELECTRA text encoder
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from dataclasses import dataclass
 
@@ -145,7 +146,7 @@ class SessionEncoder:
     node stores carry ``x`` ids) on the encoder's device."""
 
     def __init__(self, cfg: EncoderConfig, weights: dict, device=None, use_edge_weight: bool = False,
-                 debug_nan_checks: bool = False):
+                 debug_nan_checks: bool = False, fused: bool = True):
         cfg.validate()
         if not torch.cuda.is_available():
             raise _lib.SssError("no HIP device available: the encoder runs on MI355X only")
@@ -154,6 +155,7 @@ class SessionEncoder:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.use_edge_weight = use_edge_weight      # the deployed path passes none (model/model.py:317)
         self.debug_nan_checks = debug_nan_checks    # the reference's 3 host-syncing asserts
+        self.fused = fused                          # 8-launch fused kernels where the shapes allow (fused_ok)
         self.training = False
         self._prepare(weights)
 
@@ -199,9 +201,21 @@ class SessionEncoder:
             wq[0:h] = qp["lin_src"]
             wq[h] = v(qp["lin_src"], qp["att_src"])
             wq[h + 1] = v(pq["lin_dst"], pq["att_dst"])
+            # fused-path product transform (k_layer_update's column layout):
+            #   [xs_p | u = x (W_g W_ih^T) (3h) | gh = W_hh x + b_hh (3h) | a_s(pq) a_d(qp)]
+            # the GRU input transform W_ih is applied BEFORE the neighbour sum (both are linear), so the
+            # layer needs no second GEMM: gi[i] = sum_j u[j] + b_ih.  Product formed in float64.
+            w7 = torch.zeros((7 * h + ALPHA_PAD, din))
+            w7[0:h] = pq["lin_src"]
+            w7[h:4 * h] = (f64(w[f"ggc.{l}.weight"])[:din, :] @ f64(w[f"ggc.{l}.w_ih"]).T).T.float()
+            w7[4 * h:7 * h] = w[f"ggc.{l}.w_hh"][:, :din]
+            w7[7 * h] = v(pq["lin_src"], pq["att_src"])
+            w7[7 * h + 1] = v(qp["lin_dst"], qp["att_dst"])
+            b7 = torch.zeros(7 * h + ALPHA_PAD)
+            b7[4 * h:7 * h] = w[f"ggc.{l}.b_hh"]
             self.layers.append(dict(
                 wp=d(wp), bp=d(bp), wq=d(wq), w_ih=d(w[f"ggc.{l}.w_ih"]), b_ih=d(w[f"ggc.{l}.b_ih"]),
-                bias_qp=d(qp["bias"]), bias_pq=d(pq["bias"]), din=din))
+                bias_qp=d(qp["bias"]), bias_pq=d(pq["bias"]), din=din, w7=d(w7), b7=d(b7)))
         self.pool = dict(
             wq=d(w["pool.query_lin.w"]), bq=d(w["pool.query_lin.b"]),
             wp=d(w["pool.product_lin.w"]), bp=d(w["pool.product_lin.b"]),
@@ -277,9 +291,10 @@ class SessionEncoder:
         _lib.check(L.sss_segment_ptr(pb.q_batch.data_ptr(), pb.Nq, pb.B, pb.qptr.data_ptr(), self._st()), "sss_segment_ptr")
         return pb
 
-    def _features(self, ids, feat, table, n):
+    def _features(self, ids, feat, table, n, buf=None):
         W = self.cfg.node_width
-        buf = torch.empty((n, W), dtype=torch.float32, device=self.device)
+        if buf is None:
+            buf = torch.empty((n, W), dtype=torch.float32, device=self.device)
         if feat is not None:
             buf[:, :self.cfg.d_in] = feat.to(self.device, torch.float32)
         else:
@@ -290,12 +305,137 @@ class SessionEncoder:
             _lib.check(rc, "sss_gather_rows")
         return buf
 
+    # ------------------------------------------------------------------ fused path (8 launches)
+    def fused_ok(self) -> bool:
+        """Shapes the fused kernels cover (one float4 column per lane: h, d_out <= 256); wider
+        models -- the reference's h = 800, D = 1600 -- take the per-op kernels."""
+        return self.fused and self.cfg.h <= 256 and self.cfg.d_out <= 256 and self.cfg.d_out % 4 == 0
+
+    def _workspace(self, pb, fresh_nodes):
+        """Intermediate buffers of the fused forward, kept with the prepared batch (no per-forward
+        allocation); the node buffers are allocated fresh when the caller asked for them."""
+        cfg, dev = self.cfg, self.device
+        h, D, P, W = cfg.h, cfg.d_out, cfg.max_seq_len, cfg.node_width
+        ws = getattr(pb, "_ws", None)
+        if ws is None:
+            e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            ldl = (D - P + 3) // 4 * 4
+            n_exp = pb.n_clicks + pb.Nq
+            ws = dict(NQ=e(pb.Nq, W), NP=e(pb.Np, W), Yp=e(pb.Np, 7 * h + ALPHA_PAD), Yq=e(pb.Nq, h + ALPHA_PAD),
+                      lin_p=e(pb.Np, ldl), lin_q=e(pb.Nq, ldl), node=e(n_exp, D), coarse=e(pb.B, D), A=e(n_exp, D),
+                      Bc=e(pb.B, D), calls={})
+            pb._ws = ws
+        if fresh_nodes:
+            ws = dict(ws, NQ=torch.empty((pb.Nq, W), dtype=torch.float32, device=dev),
+                      NP=torch.empty((pb.Np, W), dtype=torch.float32, device=dev), calls={})
+        return ws
+
+    def _fused_calls(self, pb, ws, gather):
+        """ctypes argument blocks of the 7 launches that do not depend on the output tensor,
+        built once per (prepared batch, workspace)."""
+        key = "gather" if gather else "rows"
+        if key in ws["calls"]:
+            return ws["calls"][key]
+        cfg = self.cfg
+        h, D, P, W = cfg.h, cfg.d_out, cfg.max_seq_len, cfg.node_width
+        NQ, NP, Yp, Yq = ws["NQ"], ws["NP"], ws["Yp"], ws["Yq"]
+        P_ = _lib.LinearProblem
+
+        def prob(x, w, bias, y, n, m, ids=None, table=None, xcopy=None):
+            return P_(x=0 if x is None else x.data_ptr(), ldx=0 if x is None else x.stride(0),
+                      ids=0 if ids is None else ids.data_ptr(), table=0 if table is None else table.data_ptr(),
+                      xcopy=0 if xcopy is None else xcopy.data_ptr(), ld_xcopy=0 if xcopy is None else xcopy.stride(0),
+                      w=w.data_ptr(), ldw=w.stride(0), bias=0 if bias is None else bias.data_ptr(),
+                      y=y.data_ptr(), ldy=y.stride(0), n=n, m=m, reserved=0)
+
+        steps, keep = [], []
+        for l, lw in enumerate(self.layers):
+            off = 0 if l == 0 else cfg.d_in + (l - 1) * h
+            din = lw["din"]
+            xin_p, xin_q = NP[:, off:off + din], NQ[:, off:off + din]
+            if l == 0 and gather:
+                pp = prob(None, lw["w7"], lw["b7"], Yp, pb.Np, 7 * h + 2, pb.p_ids, self.item_table, xin_p)
+                pq = prob(None, lw["wq"], None, Yq, pb.Nq, h + 2, pb.q_ids, self.query_table, xin_q)
+            else:
+                pp = prob(xin_p, lw["w7"], lw["b7"], Yp, pb.Np, 7 * h + 2)
+                pq = prob(xin_q, lw["wq"], None, Yq, pb.Nq, h + 2)
+            arr = (P_ * 2)(pp, pq)
+            out_p = NP[:, cfg.d_in + l * h: cfg.d_in + (l + 1) * h]
+            out_q = NQ[:, cfg.d_in + l * h: cfg.d_in + (l + 1) * h]
+            rp_qp, c_qp, _ = pb.csr_qp
+            rp_pq, c_pq, _ = pb.csr_pq
+            rp_pp, c_pp, w_pp = pb.csr_pp
+            la = _lib.LayerArgs(yp=Yp.data_ptr(), ld_yp=Yp.stride(0), yq=Yq.data_ptr(), ld_yq=Yq.stride(0), h=h, d_x=din,
+                                rowptr_qp=rp_qp.data_ptr(), col_qp=c_qp.data_ptr(), rowptr_pp=rp_pp.data_ptr(),
+                                col_pp=c_pp.data_ptr(), w_pp=0 if w_pp is None else w_pp.data_ptr(),
+                                bias_qp=lw["bias_qp"].data_ptr(), b_ih=lw["b_ih"].data_ptr(),
+                                xin_p=xin_p.data_ptr(), ld_xin=NP.stride(0), out_p=out_p.data_ptr(), ld_out_p=NP.stride(0),
+                                np=pb.Np, rowptr_pq=rp_pq.data_ptr(), col_pq=c_pq.data_ptr(),
+                                bias_pq=lw["bias_pq"].data_ptr(), out_q=out_q.data_ptr(), ld_out_q=NQ.stride(0), nq=pb.Nq)
+            steps.append(("lin", arr, 2, din))
+            steps.append(("layer", la))
+            keep += [arr, la]
+        pw = self.pool
+        Dl = D - P
+        arr = (P_ * 2)(prob(NP, pw["wp"], pw["bp"], ws["lin_p"], pb.Np, Dl), prob(NQ, pw["wq"], pw["bq"], ws["lin_q"], pb.Nq, Dl))
+        steps.append(("lin", arr, 2, W))
+        steps.append(("expand",))
+        n_exp = pb.n_clicks + pb.Nq
+        arr2 = (P_ * 2)(prob(ws["node"], pw["wn"], pw["bn"], ws["A"], n_exp, D), prob(ws["coarse"], pw["wc"], None, ws["Bc"], pb.B, D))
+        steps.append(("lin", arr2, 2, D))
+        ws["calls"][key] = steps
+        return steps
+
+    def _forward_fused(self, pb, get_node, query_node_mask, product_node_mask, l2_normalize):
+        cfg, L, dev = self.cfg, _lib.lib(), self.device
+        h, D, P, W = cfg.h, cfg.d_out, cfg.max_seq_len, cfg.node_width
+        ws = self._workspace(pb, get_node)
+        NQ, NP = ws["NQ"], ws["NP"]
+        masked = query_node_mask is not None or product_node_mask is not None
+        gather = pb.q_feat is None and pb.p_feat is None and not masked
+        if not gather:      # features given / masked inputs: materialise slice 0 first (per-op kernels)
+            self._features(pb.q_ids, pb.q_feat, self.query_table, pb.Nq, NQ)
+            self._features(pb.p_ids, pb.p_feat, self.item_table, pb.Np, NP)
+            if query_node_mask is not None:
+                NQ[:, :cfg.d_in] *= query_node_mask.to(dev, torch.float32).view(-1, 1)
+            if product_node_mask is not None:
+                NP[:, :cfg.d_in] *= product_node_mask.to(dev, torch.float32).view(-1, 1)
+        elif self.item_table is None or self.query_table is None:
+            raise _lib.SssError("no feature table in the weights and no .feat on the batch")
+        st = self._st()
+        pw = self.pool
+        for step in self._fused_calls(pb, ws, gather):
+            if step[0] == "lin":
+                _lib.check(L.sss_linear_grouped(step[1], step[2], step[3], st), "sss_linear_grouped")
+            elif step[0] == "layer":
+                _lib.check(L.sss_hetero_layer_update(ctypes.byref(step[1]), st), "sss_hetero_layer_update")
+            else:
+                rc = L.sss_pool_expand_mean(ws["lin_p"].data_ptr(), ws["lin_q"].data_ptr(), ws["lin_p"].stride(0),
+                                            pb.src_row.data_ptr(), pb.pos_id.data_ptr(), pb.pptr.data_ptr(), pb.qptr.data_ptr(),
+                                            pb.n_clicks, pb.B, D - P, P, pw["pos"].data_ptr(), ws["node"].data_ptr(), D,
+                                            ws["coarse"].data_ptr(), D, st)
+                _lib.check(rc, "sss_pool_expand_mean")
+        out = torch.empty((pb.B, D), dtype=torch.float32, device=dev)
+        rc = L.sss_pool_attention(ws["node"].data_ptr(), D, ws["A"].data_ptr(), D, ws["Bc"].data_ptr(), D, pw["watt"].data_ptr(),
+                                  pb.pptr.data_ptr(), pb.qptr.data_ptr(), pb.n_clicks, pb.B, D, 1 if l2_normalize else 0,
+                                  1e-6, out.data_ptr(), D, st)
+        _lib.check(rc, "sss_pool_attention")
+        return out, NQ, NP
+
     @torch.no_grad()
-    def forward(self, data, query_node_mask=None, product_node_mask=None, get_node=False, get_token=False):
+    def forward(self, data, query_node_mask=None, product_node_mask=None, get_node=False, get_token=False,
+                l2_normalize=False):
+        """``l2_normalize=True`` (extension) returns ``normalize(forward(data))`` -- the reference's
+        util_amazon_filtered.normalize -- fused into the last pooling kernel."""
         cfg, L, dev = self.cfg, _lib.lib(), self.device
         h, D, P, W = cfg.h, cfg.d_out, cfg.max_seq_len, cfg.node_width
         pb = self.prepare(data)
         Nq, Np, B = pb.Nq, pb.Np, pb.B
+        if self.fused_ok():
+            out, NQ, NP = self._forward_fused(pb, get_node, query_node_mask, product_node_mask, l2_normalize)
+            if self.debug_nan_checks and (torch.isnan(NQ).any() or torch.isnan(NP).any()):
+                raise RuntimeError("nan in node embedding")
+            return self._pack(out, NQ, NP, get_node, get_token)
 
         NQ = self._features(pb.q_ids, pb.q_feat, self.query_table, Nq)   # [Nq, W]; slice 0 = input features
         NP = self._features(pb.p_ids, pb.p_feat, self.item_table, Np)    # embedding lookup (NodeAsinEmbedding)
@@ -365,6 +505,13 @@ class SessionEncoder:
                                 out.data_ptr(), out.stride(0), self._st())
         _lib.check(rc, "sss_segment_pool(att)")
 
+        if l2_normalize:
+            from .index import normalize_
+            normalize_(out)
+        return self._pack(out, NQ, NP, get_node, get_token)
+
+    @staticmethod
+    def _pack(out, NQ, NP, get_node, get_token):
         node_embedding = {"query": NQ, "product": NP}
         session_level_token_emb = {}            # the cross-attention branch is commented out upstream
         if not get_node and not get_token:

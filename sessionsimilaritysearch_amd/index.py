@@ -180,10 +180,11 @@ class FlatIndex:
     def fused_ok(self, k: int) -> bool:
         return self.metric == "ip" and self.d in FUSED_DIMS[self.dtype] and 0 < k <= FUSED_MAX_K and self.ntotal > 0
 
-    def search_fused(self, q: torch.Tensor, k: int, out=None):
+    def search_fused(self, q: torch.Tensor, k: int, out=None, unproven_count=None):
         """Enqueue the fused MFMA scoring + top-k on the current stream; no host sync.
         Returns (D [nq,k] f32, I [nq,k] i64, status [nq] i32) CUDA tensors; rows with
-        status != 0 must be re-run with ``search_exhaustive`` (``search`` does that)."""
+        status != 0 must be re-run with ``search_exhaustive`` (``search`` does that).
+        ``unproven_count``: optional CUDA int32 [1] tensor, incremented once per unproven query."""
         L = _lib.lib()
         _lib.require_cuda(q, "q", self._tdtype)
         nq, n = q.shape[0], self.ntotal
@@ -197,6 +198,7 @@ class FlatIndex:
         ws = self._workspace(nbytes)
         rc = L.sss_ip_topk(q.data_ptr(), nq, self._xb.data_ptr(), n, self.d, k, DTYPE_CODE[self.dtype], self.id_offset,
                            self.corpus_max_norm(), D.data_ptr(), I.data_ptr(), status.data_ptr(),
+                           0 if unproven_count is None else unproven_count.data_ptr(),
                            ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
         _lib.check(rc, "sss_ip_topk")
         return D, I, status
