@@ -2,9 +2,17 @@
 """Headline benchmark: session queries/sec + recall@10, 1M-session corpus, d=128.
 
 One "step" = one pass of the hot path over one batch of 1024 synthetic query sessions that are
-already resident in HBM as a batched graph: GNN embed (gather -> HeteroGGNN x2 ->
-positional-attention pooling) -> L2-normalise -> fused MFMA scoring + top-10 against this
-rank's corpus shard -> (N > 1) RCCL all-gather of the packed per-shard results -> merge.
+already resident in HBM as a prepared batched graph (CSR adjacencies + pooling indices: the
+reference builds its graphs on the host before model.forward too, test_amazon_filterd.py:546-551):
+GNN embed (table gather -> HeteroGGNN x2 -> positional-attention pooling -> L2-normalise, 8
+launches) -> fused MFMA scoring + top-10 against this rank's corpus shard -> (N > 1) RCCL
+all-gather of the packed per-shard results -> merge.
+
+The timed call is the asynchronous exact search (`ShardedFlatIndex.search_async`): every query's
+result carries an on-device proof of exactness and unproven queries are COUNTED on the device
+(`unproven_queries` in the line, summed over all timed steps and ranks).  With that count at 0
+the step did exactly the work of the synchronous `ShardedFlatIndex.search` minus one host sync;
+if it is not 0 the bench re-times with the synchronous API and reports that instead.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -16,8 +24,10 @@ The corpus itself is built before the timed region by embedding synthetic sessio
 same encoder (index build; not timed, as in the reference where the index is built once).
 
 Extra JSON objects (see DESIGN.md "measurement"):
-  roofline     -- dominant kernel k_ip_topk_f32<128>: algorithmic FLOPs per launch / its mean
-                  duration, hipEvent-timed on its own stream inside the timed region.
+  roofline     -- dominant kernel k_scan<512,*,f32>: algorithmic FLOPs per launch / its mean
+                  duration, hipEvent-timed on its own stream inside the timed region; `traffic` =
+                  HBM bytes per launch from the committed rocprofv3 PMC passes of this command
+                  (profiles/r02_traffic.json; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM").
   cpu_baseline -- the oracle's restatement of the reference CPU path (torch CPU encoder +
                   faiss-shaped blocked SGEMM/top-k search) on this host's cores, rank 0, N=1 only.
 """
@@ -40,11 +50,12 @@ from sessionsimilaritysearch_amd import _lib  # noqa: E402
 from sessionsimilaritysearch_amd import sessions as S  # noqa: E402
 from sessionsimilaritysearch_amd.distributed import HipEngine, ShardedFlatIndex, shard_range  # noqa: E402
 from sessionsimilaritysearch_amd.encoder import EncoderConfig, SessionEncoder, init_weights  # noqa: E402
-from sessionsimilaritysearch_amd.index import FlatIndex, normalize_  # noqa: E402
+from sessionsimilaritysearch_amd.index import FlatIndex, normalize_, to_bf16  # noqa: E402
 
 CONFIG_INDEX = 2                 # seeds: SURVEY.md 8(d) (20260000 + config index, 1234 + config index)
 BLOCK = 32768                    # sessions generated / embedded per block (seeded per block)
 FP32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense f32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 
 def log(rank, *a):
@@ -87,6 +98,9 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--recall-queries", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="index element type (bf16 + --d 256 --nq 4096 --corpus-source random = config C5)")
+    ap.add_argument("--d", type=int, default=128)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,7 +123,7 @@ def main():
             dist.init_process_group(backend)
 
     L = _lib.lib()
-    d, k, nq, n_total = 128, args.k, args.nq, args.corpus_rows
+    d, k, nq, n_total = args.d, args.k, args.nq, args.corpus_rows
     cfg = EncoderConfig(d_in=d, h=d, n_layers=2, d_out=d, self_loop_rule="none")
     weights = init_weights(cfg, 1234 + CONFIG_INDEX)
     enc = SessionEncoder(cfg, weights, device).eval()
@@ -120,39 +134,59 @@ def main():
     xb = build_corpus_shard(enc, cfg, n_total, lo, hi, device, args.corpus_source)
     torch.cuda.synchronize()
     log(rank, f"corpus shard rows [{lo},{hi}) built in {time.time() - t0:.1f}s")
-    index = FlatIndex(d, "ip", device).adopt(xb, id_offset=lo)
+    if args.dtype == "bf16":
+        xb = to_bf16(xb)
+    index = FlatIndex(d, "ip", device, dtype=args.dtype).adopt(xb, id_offset=lo)
     index.corpus_max_norm()
-    sharded = ShardedFlatIndex(HipEngine(index), device)
+    engine = HipEngine(index)
+    sharded = ShardedFlatIndex(engine, device)
 
     # ---- query batch, resident in HBM
     q_acts = S.synthetic_actions(nq, 20269999, cfg.n_items, cfg.n_query)
     q_host = S.build_batch(q_acts)
     qbatch = enc.prepare(q_host.to(device))      # batched CSR session graph, resident in HBM
 
-    def step():
-        emb = enc(qbatch)
-        normalize_(emb)
+    def embed():
+        emb = enc(qbatch, l2_normalize=True)
+        return to_bf16(emb) if args.dtype == "bf16" else emb
+
+    def step_async():
+        emb = embed()
         return (emb,) + tuple(sharded.search_async(emb, k))
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    _lib.check(L.sss_profile_enable(1), "profile_enable")
+    def step_sync():
+        emb = embed()
+        return (emb,) + tuple(sharded.search(emb, k)) + (None,)
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        emb, D, I, status = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(step):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        engine.unproven.zero_()
+        _lib.check(L.sss_profile_enable(1), "profile_enable")
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        unp = torch.tensor([float(engine.unproven.item()), el], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(unp[:1])
+            dist.all_reduce(unp[1:], op=dist.ReduceOp.MAX)
+        return res, float(unp[1].item()), int(unp[0].item())
+
+    api = "search_async + on-device unproven counter"
+    (emb, D, I, status), elapsed, unproven = timed_region(step_async)
+    if unproven != 0:       # some query needed the exhaustive path: report the synchronous exact API instead
+        tot_ms, launches = ctypes.c_double(0), ctypes.c_int(0)
+        L.sss_profile_read(ctypes.byref(tot_ms), ctypes.byref(launches))
+        api = "search (synchronous exact API; %d queries were unproven in the async run)" % unproven
+        (emb, D, I, status), elapsed, _ = timed_region(step_sync)
 
     tot_ms, launches = ctypes.c_double(0), ctypes.c_int(0)
     _lib.check(L.sss_profile_read(ctypes.byref(tot_ms), ctypes.byref(launches)), "profile_read")
@@ -169,19 +203,14 @@ def main():
             fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
-    embed_ms = timed(lambda: normalize_(enc(qbatch)))
+    embed_ms = timed(embed)
     search_ms = timed(lambda: sharded.search_async(emb, k))
 
-    # ---- exactness: unproven count + recall@10 / id equality against the oracle
-    unproven = int(status.sum().item())
-    if world > 1:
-        t = torch.tensor([unproven], dtype=torch.int64, device=device)
-        dist.all_reduce(t)
-        unproven = int(t.item())
+    # ---- exactness: recall@10 / id equality against the oracle (canonical scores of the stored vectors)
     from oracle import search_ref as sr, gnn_ref       # checker + CPU baseline only
     nrq = min(args.recall_queries, nq)
-    q_np = emb[:nrq].cpu().numpy()
-    Dl, Il = sr.search_exact(q_np, xb.cpu().numpy(), k, id_offset=lo)
+    q_np = emb[:nrq].float().cpu().numpy()
+    Dl, Il = sr.search_exact(q_np, xb.float().cpu().numpy(), k, id_offset=lo)
     if world > 1:
         pack = torch.cat([torch.from_numpy(Il).to(device).double(), torch.from_numpy(Dl).to(device).double()], 1)
         allp = [torch.empty_like(pack) for _ in range(world)]
@@ -203,7 +232,7 @@ def main():
         # more threads than that only thrash (measured: 256 threads -> 100x slower)
         cores = max(1, min(len(os.sched_getaffinity(0)), 16))
         torch.set_num_threads(cores)
-        corpus_cpu = xb.cpu().numpy()
+        corpus_cpu = xb.float().cpu().numpy()
         qb_cpu = q_host.to_torch("cpu")
 
         def clock(fn, reps):
@@ -223,23 +252,34 @@ def main():
                          f"float32 SGEMM/top-k (faiss-shaped) over {sample} of {n_total} corpus rows "
                          f"({t_search:.3f}s, scaled linearly to the full corpus)"}
 
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if os.path.exists(tpath):       # per-launch HBM bytes measured by the committed rocprofv3 --pmc passes
+        with open(tpath) as f:
+            tj = json.load(f)
+        key = f"{args.dtype}:{d}:{nq}:{hi - lo}"
+        if key in tj:
+            traffic = tj[key]
+    peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         line = {
             "metric": "session queries/sec", "value": round(nq * args.steps / elapsed, 1), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"{n_total}-session corpus d=128 ({args.corpus_source}), GNN embed (2-layer "
-                                   f"HeteroGGNN + positional-attention pooling) + cosine top-{k}, query batch {nq}",
+            "config": {"workload": f"{n_total}-session corpus d={d} ({args.corpus_source}), GNN embed (2-layer "
+                                   f"HeteroGGNN + positional-attention pooling + normalise) + cosine top-{k}, query batch {nq}; "
+                                   "query graphs prepared (CSR) before the timed region",
+                       "timed_api": api,
                        "corpus_rows": n_total, "rows_per_gpu": hi - lo, "d": d, "k": k, "query_batch": nq,
                        "parallelism": f"corpus row-sharded x{world}, 1 all-gather + merge" if world > 1 else "single GPU"},
             "recall_at_10": round(recall, 6), "ids_bit_exact": ids_exact, "max_score_err": score_err,
             "recall_queries_checked": nrq, "unproven_queries": unproven,
             "stage_ms": {"embed_normalize": round(embed_ms, 4), "score_topk_merge": round(search_ms, 4)},
-            "roofline": {"bound": "mfma", "kernel": "k_ip_topk_f32<128>", "achieved": round(achieved, 2),
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": f"k_scan<{d * (4 if args.dtype == 'f32' else 2)},*,{args.dtype}>",
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel_ms": round(kern_ms, 4), "launches": launches.value,
                          "flop_per_launch": flop_per_launch},
             "cpu_baseline": cpu,

@@ -464,9 +464,10 @@ template <int KC>
 __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
     constexpr int CPR = KC / 4;
     constexpr int NLD = LT * CPR / 256;
+    constexpr int RS = CPR < 16 ? 16 : CPR;     // LDS row stride in 16-byte chunks (the XOR swizzle spans 16)
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     float* lx = lds_raw;
-    float* lw = lds_raw + LT * 128;
+    float* lw = lds_raw + LT * RS * 4;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
@@ -493,8 +494,8 @@ __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
     const int xr = wr * 32 + r, wrow = wc * 32 + r;
 
     f32x16 acc = {0};
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        f32x4 sx[NLD], sw[NLD];
+    f32x4 sx[NLD], sw[NLD];          // register staging of one K chunk (ext-vector type: stays in VGPRs)
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int p = tid + 256 * i;
@@ -507,24 +508,28 @@ __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
             if (ids && xcopy && col0 == 0 && row0 + tr < N)          // the gathered rows = slice 0 of the node buffer
                 *reinterpret_cast<f32x4*>(xcopy + gr * ldc + k0 + c * 4) = sx[i];
         }
-        if (k0 > 0) __syncthreads();
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        if (k0 > 0) __syncthreads();                         // previous chunk fully consumed
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int p = tid + 256 * i;
             const int tr = p / CPR, c = p % CPR;
             const int cs = c ^ (tr & 15);
-            *reinterpret_cast<f32x4*>(lx + (tr * 32 + cs) * 4) = sx[i];
-            *reinterpret_cast<f32x4*>(lw + (tr * 32 + cs) * 4) = sw[i];
+            *reinterpret_cast<f32x4*>(lx + (tr * RS + cs) * 4) = sx[i];
+            *reinterpret_cast<f32x4*>(lw + (tr * RS + cs) * 4) = sw[i];
         }
         __syncthreads();
-        float4 a = *reinterpret_cast<const float4*>(lx + (xr * 32 + (h ^ (xr & 15))) * 4);
-        float4 b = *reinterpret_cast<const float4*>(lw + (wrow * 32 + (h ^ (wrow & 15))) * 4);
+        if (k0 + KC < K) fetch(k0 + KC);                     // next chunk's loads fly under this chunk's MFMAs
+        float4 a = *reinterpret_cast<const float4*>(lx + (xr * RS + (h ^ (xr & 15))) * 4);
+        float4 b = *reinterpret_cast<const float4*>(lw + (wrow * RS + (h ^ (wrow & 15))) * 4);
 #pragma unroll
         for (int u = 0; u < KC / 8; ++u) {
             float4 na = a, nb = b;
             if (u + 1 < KC / 8) {
-                na = *reinterpret_cast<const float4*>(lx + (xr * 32 + ((2 * u + 2 + h) ^ (xr & 15))) * 4);
-                nb = *reinterpret_cast<const float4*>(lw + (wrow * 32 + ((2 * u + 2 + h) ^ (wrow & 15))) * 4);
+                na = *reinterpret_cast<const float4*>(lx + (xr * RS + ((2 * u + 2 + h) ^ (xr & 15))) * 4);
+                nb = *reinterpret_cast<const float4*>(lw + (wrow * RS + ((2 * u + 2 + h) ^ (wrow & 15))) * 4);
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
@@ -573,15 +578,22 @@ __device__ __forceinline__ float leaky02(float v) { return v > 0.f ? v : 0.2f * 
 // softmax-weighted sum over the incoming edges of one target: returns sum_e softmax_e * xs[col[e]][c4] + bias
 __device__ __forceinline__ float4 gat_row(const float* xs, long ld, const float* a_src_col, float ad, const int* col,
                                           int e0, int e1, int c4, const float* bias) {
-    float mx = -INFINITY;
-    for (int e = e0; e < e1; ++e) mx = fmaxf(mx, leaky02(a_src_col[(long)col[e] * ld] + ad));
-    float den = 0.f;
+    // one pass (online softmax): a new maximum rescales what has been summed so far, so every
+    // edge's index / score / row is loaded exactly once
+    float mx = -INFINITY, den = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int e = e0; e < e1; ++e) {
         const long j = col[e];
-        const float ex = expf(leaky02(a_src_col[j * ld] + ad) - mx);
+        const float v = leaky02(a_src_col[j * ld] + ad);
+        const float4 x = *reinterpret_cast<const float4*>(xs + j * ld + c4);
+        if (v > mx) {
+            const float sc = expf(mx - v);                 // exp(-inf) = 0 on the first edge
+            den *= sc; acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
+            mx = v;
+        }
+        const float ex = expf(v - mx);
         den += ex;
-        acc = f4_fma(ex, *reinterpret_cast<const float4*>(xs + j * ld + c4), acc);
+        acc = f4_fma(ex, x, acc);
     }
     const float inv = 1.f / (den + 1e-16f);
     const float4 b = *reinterpret_cast<const float4*>(bias + c4);
@@ -658,22 +670,38 @@ __global__ __launch_bounds__(256) void k_pool_expand_mean(const float* __restric
     const int D = Dl + P, c4 = sub * 4;
     if (g >= n_graphs || c4 >= D) return;
     const int p0 = pptr[g], p1 = pptr[g + 1], q0 = qptr[g], q1 = qptr[g + 1];
-    const int cnt = (p1 - p0) + (q1 - q0);
+    const int np_ = p1 - p0, cnt = np_ + (q1 - q0);
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t = 0; t < cnt; ++t) {
-        const bool is_p = t < (p1 - p0);
-        const long e = is_p ? (long)(p0 + t) : n_clicks + (long)(q0 + t - (p1 - p0));
-        const float* lin = (is_p ? lin_p : lin_q) + (long)src_row[e] * ld_lin;
+    // Rows are independent: four rows' loads are issued before the first tanh so their latencies
+    // overlap (the per-row chain src_row -> lin row would otherwise serialise the whole graph).
+    auto row_of = [&](int t) -> long { return t < np_ ? (long)(p0 + t) : n_clicks + (long)(q0 + t - np_); };
+    auto load_row = [&](int t, float (&v)[4], long& e) {
+        e = row_of(t);
+        const float* lin = (t < np_ ? lin_p : lin_q) + (long)src_row[e] * ld_lin;
         const float* pe = pos_emb + (long)pos_id[e] * P;
-        float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = c4 + u;
-            v[u] = tanhf(c < Dl ? lin[c] : pe[c - Dl]);
+            v[u] = c < Dl ? lin[c] : pe[c - Dl];
         }
-        const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+    };
+    auto finish_row = [&](const float (&v)[4], long e) {
+        const float4 o = make_float4(tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3]));
         *reinterpret_cast<float4*>(node + e * ld_node + c4) = o;
         m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+    };
+    int t = 0;
+    for (; t + 4 <= cnt; t += 4) {
+        float v0[4], v1[4], v2[4], v3[4];
+        long e0, e1, e2, e3;
+        load_row(t, v0, e0); load_row(t + 1, v1, e1); load_row(t + 2, v2, e2); load_row(t + 3, v3, e3);
+        finish_row(v0, e0); finish_row(v1, e1); finish_row(v2, e2); finish_row(v3, e3);
+    }
+    for (; t < cnt; ++t) {
+        float v0[4];
+        long e0;
+        load_row(t, v0, e0);
+        finish_row(v0, e0);
     }
     const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
     *reinterpret_cast<float4*>(coarse + g * ld_coarse + c4) = make_float4(m.x * inv, m.y * inv, m.z * inv, m.w * inv);
@@ -699,19 +727,31 @@ __global__ __launch_bounds__(256) void k_pool_attention(const float* __restrict_
     const int cnt = (p1 - p0) + (q1 - q0);
     float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = w4, acc = w4;
     if (live) { w4 = *reinterpret_cast<const float4*>(watt + c4); b4 = *reinterpret_cast<const float4*>(Bc + g * ld_b + c4); }
-    for (int t = 0; t < cnt; ++t) {
-        const long e = t < (p1 - p0) ? (long)(p0 + t) : n_clicks + (long)(q0 + t - (p1 - p0));
-        float part = 0.f;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) {
-            const float4 a = *reinterpret_cast<const float4*>(Aa + e * ld_a + c4);
+    auto row_of = [&](int t) -> long { return t < (p1 - p0) ? (long)(p0 + t) : n_clicks + (long)(q0 + t - (p1 - p0)); };
+    auto load_row = [&](int t, float4& a, float4& v) {
+        a = make_float4(0.f, 0.f, 0.f, 0.f); v = a;
+        if (live && t < cnt) {
+            const long e = row_of(t);
+            a = *reinterpret_cast<const float4*>(Aa + e * ld_a + c4);
             v = *reinterpret_cast<const float4*>(node + e * ld_node + c4);
-            part = w4.x * sigmoidf_(a.x + b4.x) + w4.y * sigmoidf_(a.y + b4.y) + w4.z * sigmoidf_(a.z + b4.z) +
-                   w4.w * sigmoidf_(a.w + b4.w);
         }
+    };
+    auto finish_row = [&](const float4& a, const float4& v) {      // every lane of the group takes part in the shuffles
+        float part = live ? w4.x * sigmoidf_(a.x + b4.x) + w4.y * sigmoidf_(a.y + b4.y) + w4.z * sigmoidf_(a.z + b4.z) +
+                                w4.w * sigmoidf_(a.w + b4.w) : 0.f;
 #pragma unroll
         for (int o = LPR / 2; o > 0; o >>= 1) part += __shfl_xor(part, o);
         acc = f4_fma(part, v, acc);
+    };
+    // cnt is uniform inside a lane group but differs between the groups of a wave: pad to the
+    // wave-wide maximum so the shuffles stay convergent; padded rows load nothing and add 0.
+    int cmax = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o));
+    for (int t = 0; t < cmax; t += 4) {                             // four rows' loads in flight
+        float4 a0, v0, a1, v1, a2, v2, a3, v3;
+        load_row(t, a0, v0); load_row(t + 1, a1, v1); load_row(t + 2, a2, v2); load_row(t + 3, a3, v3);
+        finish_row(a0, v0); finish_row(a1, v1); finish_row(a2, v2); finish_row(a3, v3);
     }
     const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
     acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
@@ -742,18 +782,11 @@ int linear_grouped(LinBatch& b, hipStream_t st) {
     }
     for (int i = b.nprob; i < 4; ++i) { b.p[i] = b.p[0]; b.p[i].tile_begin = 0x7fffffff; }
     if (total == 0) return SSS_OK;
-    const int lds = 2 * LT * 128 * 4;
-    static bool attr_done[64] = {};
-    int dev = 0; (void)hipGetDevice(&dev); if (dev < 0 || dev >= 64) dev = 0;
-    if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_grouped<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_grouped<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_grouped<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done[dev] = true;
-    }
-    if (b.K % 128 == 0) hipLaunchKernelGGL(k_linear_grouped<128>, dim3((unsigned)total), dim3(256), lds, st, b);
-    else if (b.K % 64 == 0) hipLaunchKernelGGL(k_linear_grouped<64>, dim3((unsigned)total), dim3(256), lds, st, b);
-    else hipLaunchKernelGGL(k_linear_grouped<32>, dim3((unsigned)total), dim3(256), lds, st, b);
+    // K chunks of 64: 32 KiB of LDS per workgroup, so up to five workgroups share a CU and their
+    // load / MFMA / store phases overlap (these launches are latency-bound, not FLOP-bound)
+    const int lds64 = 2 * LT * 16 * 16;
+    if (b.K % 64 == 0) hipLaunchKernelGGL(k_linear_grouped<64>, dim3((unsigned)total), dim3(256), lds64, st, b);
+    else hipLaunchKernelGGL(k_linear_grouped<32>, dim3((unsigned)total), dim3(256), lds64, st, b);
     return check_launch("k_linear_grouped");
 }
 
