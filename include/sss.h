@@ -186,6 +186,18 @@ int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64
                        int64_t n_clicks, int64_t n_graphs, int d, int normalize, float eps, float* out,
                        int64_t ld_out, void* stream);
 
+/* ---- neighbour-weighted item vote: get_prediction_by_knn after the search
+ * (test_amazon_filterd.py:59-78; config C3's "aggregated top-10").  D [nq, s] fp32 and I [nq, s]
+ * int64 are a search result (I < 0 = padding, skipped); session i's distinct items are
+ * items[items_ptr[i - id_offset] .. items_ptr[i - id_offset + 1]) (the product.x of graph i).
+ * Every item of neighbour j gets weight D[j]; weights are summed per item in float64 in neighbour
+ * order; out_items [nq, k] int64 = the k heaviest items by (weight desc, first-seen order asc),
+ * -1 padded; out_weights [nq, k] float64 may be NULL.  status [nq]: 0 ok, 1 = more than 16384
+ * (neighbour, item) pairs for that query (not processed).  s < 32768. */
+int sss_knn_item_vote(const float* D, const int64_t* I, int64_t nq, int s, const int64_t* items_ptr,
+                      const int32_t* items, int64_t id_offset, int64_t n_sessions, int k,
+                      int64_t* out_items, double* out_weights, int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

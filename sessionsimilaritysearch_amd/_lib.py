@@ -48,6 +48,8 @@ _SIGNATURES = {
     "sss_segment_pool": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                  c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "sss_segment_ptr": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "sss_knn_item_vote": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     "sss_linear_grouped": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "sss_hetero_layer_update": (c_int, [c_void_p, c_void_p]),
     "sss_pool_expand_mean": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

@@ -68,6 +68,7 @@ int pool_expand_mean(const float*, const float*, long, const int*, const int*, c
                      const float*, float*, long, float*, long, hipStream_t);
 int pool_attention(const float*, long, const float*, long, const float*, long, const float*, const int*, const int*, long, long,
                    int, int, float, float*, long, hipStream_t);
+int item_vote(const float*, const long*, long, int, const long*, const int*, long, long, int, long*, double*, int*, hipStream_t);
 
 }  // namespace sss
 
@@ -183,6 +184,12 @@ int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64
                        int d, int normalize, float eps, float* out, int64_t ld_out, void* stream) {
     return sss::pool_attention(node, ld_node, a, ld_a, b, ld_b, watt, pptr, qptr, n_clicks, n_graphs, d, normalize, eps, out,
                                ld_out, ST(stream));
+}
+int sss_knn_item_vote(const float* D, const int64_t* I, int64_t nq, int s, const int64_t* items_ptr, const int32_t* items,
+                      int64_t id_offset, int64_t n_sessions, int k, int64_t* out_items, double* out_weights,
+                      int32_t* status, void* stream) {
+    return sss::item_vote(D, reinterpret_cast<const long*>(I), nq, s, reinterpret_cast<const long*>(items_ptr), items,
+                          id_offset, n_sessions, k, reinterpret_cast<long*>(out_items), out_weights, status, ST(stream));
 }
 int sss_segment_ptr(const int64_t* batch, int64_t n, int64_t n_graphs, int32_t* ptr, void* stream) {
     return sss::segment_ptr(reinterpret_cast<const long*>(batch), n, n_graphs, ptr, ST(stream));
