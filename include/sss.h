@@ -101,14 +101,16 @@ int sss_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const f
                int64_t ldy, int64_t n, int m, int k, void* stream);
 
 /* GATConv.propagate for one edge type (instantiated model/gnn.py:54):
- * CSR by target (rowptr [n_dst+1], col = source ids, int32; the PyG self-loop rewrite is already
- * applied by the caller): e = leaky_relu(a_src[j] + a_dst[i], 0.2), per-target softmax with the
- * +1e-16 of PyG, out[i] = sum_j w_ij xs[j] + bias (relu != 0: then max(.,0)).
- * a_src / a_dst are strided scalars (element i at a[i * ld]). */
+ * CSR by target (rowptr [n_dst+1], col = source ids, int32): e = leaky_relu(a_src[j] + a_dst[i], 0.2),
+ * per-target softmax with the +1e-16 of PyG, out[i] = sum_j w_ij xs[j] + bias (relu != 0: then
+ * max(.,0)).  a_src / a_dst are strided scalars (element i at a[i * ld]).
+ * n_self_loop > 0 applies PyG's GATConv(add_self_loops=True) edge rewrite on the fly, in the
+ * batch-global indices of the CSR: edges with source == target are dropped and one edge i -> i is
+ * appended for every target i < n_self_loop (= min(n_src, n_dst)); 0: the CSR is used as is. */
 int sss_gat_aggregate(const float* xs, int64_t ld_xs, const float* a_src, int64_t ld_as,
                       const float* a_dst, int64_t ld_ad, const int32_t* rowptr, const int32_t* col,
-                      int64_t n_dst, int h, const float* bias, int relu, float* out, int64_t ld_out,
-                      void* stream);
+                      int64_t n_dst, int h, const float* bias, int relu, int64_t n_self_loop, float* out,
+                      int64_t ld_out, void* stream);
 
 /* GatedGraphConv.propagate, aggr='add' (Appendix A.3; model/gnn.py:58):
  * out[i] = sum_{e in row i} (w[e] if w else 1) * m[col[e]]. */
@@ -161,7 +163,8 @@ int sss_linear_grouped(const sss_linear_problem* problems, int n_problems, int k
  * caller):  yp [np, >= 7h+2]: xs_p | u_r u_z u_n | gh_r gh_z gh_n | alpha_src(pq) alpha_dst(qp)
  *           yq [nq, >=  h+2]: xs_q | alpha_src(qp) alpha_dst(pq)
  * where u = x (W_ggc W_ih^T) -- GRU input transform applied before the (linear) neighbour sum --
- * and gh = W_hh x + b_hh.  CSR by target, int32, self-loop rewrite already applied.  h <= 256. */
+ * and gh = W_hh x + b_hh.  CSR by target, int32; n_self_loop as in sss_gat_aggregate (both GAT
+ * directions).  h <= 256. */
 typedef struct {
     const float* yp; int64_t ld_yp; const float* yq; int64_t ld_yq; int32_t h; int32_t d_x;
     const int32_t* rowptr_qp; const int32_t* col_qp; const int32_t* rowptr_pp; const int32_t* col_pp;
@@ -169,6 +172,7 @@ typedef struct {
     const float* xin_p; int64_t ld_xin; float* out_p; int64_t ld_out_p; int64_t np;
     const int32_t* rowptr_pq; const int32_t* col_pq; const float* bias_pq;
     float* out_q; int64_t ld_out_q; int64_t nq;
+    int64_t n_self_loop;
 } sss_layer_args;
 int sss_hetero_layer_update(const sss_layer_args* args, void* stream);
 
@@ -185,6 +189,35 @@ int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64
                        int64_t ld_b, const float* watt, const int32_t* pptr, const int32_t* qptr,
                        int64_t n_clicks, int64_t n_graphs, int d, int normalize, float eps, float* out,
                        int64_t ld_out, void* stream);
+
+/* ---- action table -> batched session graphs, on device: the structural part of
+ * sequence_to_graph (util_amazon_filtered.py:98-230) + Batch.from_data_list
+ * (test_amazon_filterd.py:485-488), straight into the CSR-by-target form the encoder kernels read.
+ * Input: sessions stored contiguously, sess_ptr int64 [S+1]; per action is_search uint8, item_id
+ * int64 (clicks), query_tok int64 (searches); at most 64 actions per session (*err != 0 otherwise).
+ * Step 1, sss_graph_counts: bases int32 [5][S+1] = exclusive scans over sessions of (query nodes,
+ *   product nodes, expanded product rows, click edges, unique transitions), grand totals at [.][S]
+ *   -- the caller reads the 5 totals to size the outputs; rows 2 and 0 double as the pooling's
+ *   per-graph pointers pptr / qptr, row 1 as the graph -> product-node pointer.
+ *   scratch: sss_graph_scratch_ints(S) int32.
+ * Step 2, sss_graph_fill writes every array of the sss_graph_out struct; sizes from the totals: Nq, Np, Xp =
+ *   expanded product rows, E = clicks, Epp.  It holds node features ids / batch vectors / click counts, the
+ *   three CSRs (qp: targets products, pq: targets queries, pp with count weights), and the
+ *   pooling's src_row / pos_id [Xp + Nq] (expanded product rows first, then the query nodes). */
+typedef struct {
+    int64_t* q_x; int64_t* q_batch; int32_t* q_pos;
+    int64_t* p_x; int64_t* p_batch; int64_t* p_cnt;
+    int32_t* rowptr_qp; int32_t* col_qp;
+    int32_t* rowptr_pq; int32_t* col_pq;
+    int32_t* rowptr_pp; int32_t* col_pp; float* w_pp;
+    int32_t* src_row; int32_t* pos_id;
+} sss_graph_out;
+size_t sss_graph_scratch_ints(int64_t n_sessions);
+int sss_graph_counts(const int64_t* sess_ptr, const uint8_t* is_search, const int64_t* item_id, int64_t n_sessions,
+                     int32_t* bases, int32_t* scratch, int32_t* err, void* stream);
+int sss_graph_fill(const int64_t* sess_ptr, const uint8_t* is_search, const int64_t* item_id,
+                   const int64_t* query_tok, int64_t n_sessions, const int32_t* bases,
+                   const sss_graph_out* out, void* stream);
 
 /* ---- neighbour-weighted item vote: get_prediction_by_knn after the search
  * (test_amazon_filterd.py:59-78; config C3's "aggregated top-10").  D [nq, s] fp32 and I [nq, s]

@@ -38,7 +38,7 @@ _SIGNATURES = {
     "sss_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                            c_int, c_int, c_void_p]),
     "sss_gat_aggregate": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
-                                  c_int64, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+                                  c_int64, c_int, c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "sss_csr_weighted_sum": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                      c_void_p, c_int64, c_void_p]),
     "sss_gru_combine": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p,
@@ -48,6 +48,9 @@ _SIGNATURES = {
     "sss_segment_pool": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                  c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "sss_segment_ptr": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "sss_graph_scratch_ints": (c_size_t, [c_int64]),
+    "sss_graph_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sss_graph_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "sss_knn_item_vote": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "sss_linear_grouped": (c_int, [c_void_p, c_int, c_int, c_void_p]),
@@ -66,6 +69,12 @@ class LinearProblem(ctypes.Structure):
                 ("ldy", c_int64), ("n", c_int64), ("m", c_int32), ("reserved", c_int32)]
 
 
+class GraphOut(ctypes.Structure):
+    """``sss_graph_out`` of include/sss.h."""
+    _fields_ = [(n, c_void_p) for n in ("q_x", "q_batch", "q_pos", "p_x", "p_batch", "p_cnt", "rowptr_qp", "col_qp",
+                                        "rowptr_pq", "col_pq", "rowptr_pp", "col_pp", "w_pp", "src_row", "pos_id")]
+
+
 class LayerArgs(ctypes.Structure):
     """``sss_layer_args`` of include/sss.h."""
     _fields_ = [("yp", c_void_p), ("ld_yp", c_int64), ("yq", c_void_p), ("ld_yq", c_int64), ("h", c_int32), ("d_x", c_int32),
@@ -73,7 +82,7 @@ class LayerArgs(ctypes.Structure):
                 ("w_pp", c_void_p), ("bias_qp", c_void_p), ("b_ih", c_void_p),
                 ("xin_p", c_void_p), ("ld_xin", c_int64), ("out_p", c_void_p), ("ld_out_p", c_int64), ("np", c_int64),
                 ("rowptr_pq", c_void_p), ("col_pq", c_void_p), ("bias_pq", c_void_p),
-                ("out_q", c_void_p), ("ld_out_q", c_int64), ("nq", c_int64)]
+                ("out_q", c_void_p), ("ld_out_q", c_int64), ("nq", c_int64), ("n_self_loop", c_int64)]
 
 
 def exported_symbols():

@@ -41,7 +41,7 @@ int f32_to_bf16(const float*, long, unsigned short*, hipStream_t);
 int gather_rows(const float*, const long*, long, int, float*, long, hipStream_t);
 int linear_f32(const float*, long, const float*, long, const float*, float*, long, long, int, int, hipStream_t);
 int gat_aggregate(const float*, long, const float*, long, const float*, long, const int*, const int*, long, int,
-                  const float*, int, float*, long, hipStream_t);
+                  const float*, int, long, float*, long, hipStream_t);
 int csr_weighted_sum(const float*, long, const int*, const int*, const float*, long, int, float*, long, hipStream_t);
 int gru_combine(const float*, long, const float*, long, const float*, long, int, const float*, long, long, int,
                 float*, long, hipStream_t);
@@ -62,6 +62,7 @@ struct LayerArgs {
     const int* rowptr_qp; const int* col_qp; const int* rowptr_pp; const int* col_pp; const float* w_pp;
     const float* bias_qp; const float* b_ih; const float* xin_p; long ld_xin; int d_x; float* out_p; long ld_outp; long Np;
     const int* rowptr_pq; const int* col_pq; const float* bias_pq; float* out_q; long ld_outq; long Nq;
+    long n_self_loop;
 };
 int layer_update(const LayerArgs&, hipStream_t);
 int pool_expand_mean(const float*, const float*, long, const int*, const int*, const int*, const int*, long, long, int, int,
@@ -69,6 +70,14 @@ int pool_expand_mean(const float*, const float*, long, const int*, const int*, c
 int pool_attention(const float*, long, const float*, long, const float*, long, const float*, const int*, const int*, long, long,
                    int, int, float, float*, long, hipStream_t);
 int item_vote(const float*, const long*, long, int, const long*, const int*, long, long, int, long*, double*, int*, hipStream_t);
+struct GraphOut {
+    long* q_x; long* q_batch; int* q_pos; long* p_x; long* p_batch; long* p_cnt;
+    int* rowptr_qp; int* col_qp; int* rowptr_pq; int* col_pq; int* rowptr_pp; int* col_pp; float* w_pp;
+    int* src_row; int* pos_id;
+};
+size_t graph_scratch_ints(long S);
+int graph_counts(const long*, const unsigned char*, const long*, long, int*, int*, int*, hipStream_t);
+int graph_fill(const long*, const unsigned char*, const long*, const long*, long, const int*, const GraphOut&, hipStream_t);
 
 }  // namespace sss
 
@@ -124,9 +133,9 @@ int sss_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const f
 }
 int sss_gat_aggregate(const float* xs, int64_t ld_xs, const float* a_src, int64_t ld_as, const float* a_dst,
                       int64_t ld_ad, const int32_t* rowptr, const int32_t* col, int64_t n_dst, int h,
-                      const float* bias, int relu, float* out, int64_t ld_out, void* stream) {
-    return sss::gat_aggregate(xs, ld_xs, a_src, ld_as, a_dst, ld_ad, rowptr, col, n_dst, h, bias, relu, out, ld_out,
-                              ST(stream));
+                      const float* bias, int relu, int64_t n_self_loop, float* out, int64_t ld_out, void* stream) {
+    return sss::gat_aggregate(xs, ld_xs, a_src, ld_as, a_dst, ld_ad, rowptr, col, n_dst, h, bias, relu, n_self_loop, out,
+                              ld_out, ST(stream));
 }
 int sss_csr_weighted_sum(const float* m, int64_t ld_m, const int32_t* rowptr, const int32_t* col, const float* w,
                          int64_t n_dst, int h, float* out, int64_t ld_out, void* stream) {
@@ -169,7 +178,7 @@ int sss_hetero_layer_update(const sss_layer_args* a, void* stream) {
     l.rowptr_qp = a->rowptr_qp; l.col_qp = a->col_qp; l.rowptr_pp = a->rowptr_pp; l.col_pp = a->col_pp; l.w_pp = a->w_pp;
     l.bias_qp = a->bias_qp; l.b_ih = a->b_ih; l.xin_p = a->xin_p; l.ld_xin = a->ld_xin; l.out_p = a->out_p;
     l.ld_outp = a->ld_out_p; l.Np = a->np; l.rowptr_pq = a->rowptr_pq; l.col_pq = a->col_pq; l.bias_pq = a->bias_pq;
-    l.out_q = a->out_q; l.ld_outq = a->ld_out_q; l.Nq = a->nq;
+    l.out_q = a->out_q; l.ld_outq = a->ld_out_q; l.Nq = a->nq; l.n_self_loop = a->n_self_loop;
     return sss::layer_update(l, ST(stream));
 }
 int sss_pool_expand_mean(const float* lin_p, const float* lin_q, int64_t ld_lin, const int32_t* src_row,
@@ -184,6 +193,24 @@ int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64
                        int d, int normalize, float eps, float* out, int64_t ld_out, void* stream) {
     return sss::pool_attention(node, ld_node, a, ld_a, b, ld_b, watt, pptr, qptr, n_clicks, n_graphs, d, normalize, eps, out,
                                ld_out, ST(stream));
+}
+size_t sss_graph_scratch_ints(int64_t n_sessions) { return sss::graph_scratch_ints(n_sessions); }
+int sss_graph_counts(const int64_t* sess_ptr, const uint8_t* is_search, const int64_t* item_id, int64_t n_sessions,
+                     int32_t* bases, int32_t* scratch, int32_t* err, void* stream) {
+    return sss::graph_counts(reinterpret_cast<const long*>(sess_ptr), is_search, reinterpret_cast<const long*>(item_id),
+                             n_sessions, bases, scratch, err, ST(stream));
+}
+int sss_graph_fill(const int64_t* sess_ptr, const uint8_t* is_search, const int64_t* item_id, const int64_t* query_tok,
+                   int64_t n_sessions, const int32_t* bases, const sss_graph_out* o, void* stream) {
+    if (!o) { sss::set_error("graph_fill: null outputs"); return SSS_EINVAL; }
+    sss::GraphOut g;
+    g.q_x = reinterpret_cast<long*>(o->q_x); g.q_batch = reinterpret_cast<long*>(o->q_batch); g.q_pos = o->q_pos;
+    g.p_x = reinterpret_cast<long*>(o->p_x); g.p_batch = reinterpret_cast<long*>(o->p_batch);
+    g.p_cnt = reinterpret_cast<long*>(o->p_cnt);
+    g.rowptr_qp = o->rowptr_qp; g.col_qp = o->col_qp; g.rowptr_pq = o->rowptr_pq; g.col_pq = o->col_pq;
+    g.rowptr_pp = o->rowptr_pp; g.col_pp = o->col_pp; g.w_pp = o->w_pp; g.src_row = o->src_row; g.pos_id = o->pos_id;
+    return sss::graph_fill(reinterpret_cast<const long*>(sess_ptr), is_search, reinterpret_cast<const long*>(item_id),
+                           reinterpret_cast<const long*>(query_tok), n_sessions, bases, g, ST(stream));
 }
 int sss_knn_item_vote(const float* D, const int64_t* I, int64_t nq, int s, const int64_t* items_ptr, const int32_t* items,
                       int64_t id_offset, int64_t n_sessions, int k, int64_t* out_items, double* out_weights,

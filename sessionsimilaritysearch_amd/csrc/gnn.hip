@@ -102,36 +102,38 @@ __global__ __launch_bounds__(256) void k_gat_aggregate(
     const float* __restrict__ xs, long ld_xs, const float* __restrict__ a_src, long ld_as,
     const float* __restrict__ a_dst, long ld_ad, const int* __restrict__ rowptr,
     const int* __restrict__ col, long n_dst, int h, const float* __restrict__ bias, int relu,
-    float* __restrict__ out, long ld_out) {
+    long n_self_loop, float* __restrict__ out, long ld_out) {
     const int sub = threadIdx.x % LPR;
     const long per_block = 256 / LPR;
     const int nv = h / 4;
+    auto score = [&](long j, float ad) {
+        const float v = a_src[j * ld_as] + ad;
+        return v > 0.f ? v : 0.2f * v;
+    };
     for (long i = (long)blockIdx.x * per_block + threadIdx.x / LPR; i < n_dst; i += (long)gridDim.x * per_block) {
         const int e0 = rowptr[i], e1 = rowptr[i + 1];
         const float ad = a_dst[i * ld_ad];
+        // n_self_loop > 0: PyG's self-loop rewrite on the fly (drop source == target, append one i -> i)
+        const long skip = n_self_loop > 0 ? i : -1, self = i < n_self_loop ? i : -1;
         float mx = -INFINITY;
-        for (int e = e0; e < e1; ++e) {
-            float v = a_src[(long)col[e] * ld_as] + ad;
-            v = v > 0.f ? v : 0.2f * v;
-            mx = fmaxf(mx, v);
-        }
+        for (int e = e0; e < e1; ++e)
+            if (col[e] != skip) mx = fmaxf(mx, score(col[e], ad));
+        if (self >= 0) mx = fmaxf(mx, score(self, ad));
         float den = 0.f;
-        for (int e = e0; e < e1; ++e) {
-            float v = a_src[(long)col[e] * ld_as] + ad;
-            v = v > 0.f ? v : 0.2f * v;
-            den += expf(v - mx);
-        }
+        for (int e = e0; e < e1; ++e)
+            if (col[e] != skip) den += expf(score(col[e], ad) - mx);
+        if (self >= 0) den += expf(score(self, ad) - mx);
         const float inv = 1.f / (den + 1e-16f);
         for (int c = sub; c < nv; c += LPR) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e = e0; e < e1; ++e) {
-                const long j = col[e];
-                float v = a_src[j * ld_as] + ad;
-                v = v > 0.f ? v : 0.2f * v;
-                const float w = expf(v - mx) * inv;
+            auto add = [&](long j) {
+                const float w = expf(score(j, ad) - mx) * inv;
                 const float4 x = *reinterpret_cast<const float4*>(xs + j * ld_xs + c * 4);
                 acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
-            }
+            };
+            for (int e = e0; e < e1; ++e)
+                if (col[e] != skip) add(col[e]);
+            if (self >= 0) add(self);
             if (bias) {
                 const float4 b = *reinterpret_cast<const float4*>(bias + c * 4);
                 acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
@@ -358,8 +360,8 @@ int linear_f32(const float* X, long ldx, const float* W, long ldw, const float* 
 }
 
 int gat_aggregate(const float* xs, long ld_xs, const float* a_src, long ld_as, const float* a_dst, long ld_ad,
-                  const int* rowptr, const int* col, long n_dst, int h, const float* bias, int relu, float* out,
-                  long ld_out, hipStream_t st) {
+                  const int* rowptr, const int* col, long n_dst, int h, const float* bias, int relu, long n_self_loop,
+                  float* out, long ld_out, hipStream_t st) {
     if (n_dst < 0 || h <= 0 || h % 4 || ld_xs % 4 || ld_out % 4 || ld_out < h) {
         set_error("gat_aggregate: need h %% 4 == 0 and 16-byte aligned row strides");
         return SSS_EINVAL;
@@ -367,7 +369,8 @@ int gat_aggregate(const float* xs, long ld_xs, const float* a_src, long ld_as, c
     if (n_dst == 0) return SSS_OK;
     const int lpr = lanes_for(h);
     SSS_LPR_SWITCH(lpr, hipLaunchKernelGGL(k_gat_aggregate<L>, dim3(grid_rows(n_dst, L)), dim3(256), 0, st, xs, ld_xs,
-                                           a_src, ld_as, a_dst, ld_ad, rowptr, col, n_dst, h, bias, relu, out, ld_out));
+                                           a_src, ld_as, a_dst, ld_ad, rowptr, col, n_dst, h, bias, relu, n_self_loop, out,
+                                           ld_out));
     return check_launch("k_gat_aggregate");
 }
 
@@ -567,6 +570,7 @@ struct LayerArgs {
     const int* rowptr_qp; const int* col_qp; const int* rowptr_pp; const int* col_pp; const float* w_pp;
     const float* bias_qp; const float* b_ih; const float* xin_p; long ld_xin; int d_x; float* out_p; long ld_outp; long Np;
     const int* rowptr_pq; const int* col_pq; const float* bias_pq; float* out_q; long ld_outq; long Nq;
+    long n_self_loop;                  // > 0: PyG bipartite self-loop rewrite on the fly, n = min(Nq, Np)
 };
 
 __device__ __forceinline__ float4 f4_fma(float w, float4 x, float4 a) {
@@ -575,15 +579,18 @@ __device__ __forceinline__ float4 f4_fma(float w, float4 x, float4 a) {
 }
 __device__ __forceinline__ float leaky02(float v) { return v > 0.f ? v : 0.2f * v; }
 
-// softmax-weighted sum over the incoming edges of one target: returns sum_e softmax_e * xs[col[e]][c4] + bias
+// softmax-weighted sum over the incoming edges of one target: returns sum_e softmax_e * xs[col[e]][c4] + bias.
+// self_i >= 0 applies PyG's GATConv(add_self_loops=True) edge rewrite on the fly (Appendix A.2):
+// edges whose source index equals the target index are dropped and ONE edge self_i -> target is
+// appended after the target's other edges (what remove_self_loops + add_self_loops + a stable
+// sort by target produce).
 __device__ __forceinline__ float4 gat_row(const float* xs, long ld, const float* a_src_col, float ad, const int* col,
-                                          int e0, int e1, int c4, const float* bias) {
+                                          int e0, int e1, int c4, const float* bias, long skip_i, long self_i) {
     // one pass (online softmax): a new maximum rescales what has been summed so far, so every
     // edge's index / score / row is loaded exactly once
     float mx = -INFINITY, den = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = e0; e < e1; ++e) {
-        const long j = col[e];
+    auto edge = [&](long j) {
         const float v = leaky02(a_src_col[j * ld] + ad);
         const float4 x = *reinterpret_cast<const float4*>(xs + j * ld + c4);
         if (v > mx) {
@@ -594,7 +601,12 @@ __device__ __forceinline__ float4 gat_row(const float* xs, long ld, const float*
         const float ex = expf(v - mx);
         den += ex;
         acc = f4_fma(ex, x, acc);
+    };
+    for (int e = e0; e < e1; ++e) {
+        const long j = col[e];
+        if (j != skip_i) edge(j);
     }
+    if (self_i >= 0) edge(self_i);
     const float inv = 1.f / (den + 1e-16f);
     const float4 b = *reinterpret_cast<const float4*>(bias + c4);
     return make_float4(acc.x * inv + b.x, acc.y * inv + b.y, acc.z * inv + b.z, acc.w * inv + b.w);
@@ -610,14 +622,17 @@ __global__ __launch_bounds__(256) void k_layer_update(const LayerArgs A) {
     if (t >= A.Np) {                                            // ---- query target
         const long i = t - A.Np;
         const float ad = A.Yq[i * A.ldyq + h + 1];
-        float4 o = gat_row(A.Yp, A.ldyp, A.Yp + 7 * h, ad, A.col_pq, A.rowptr_pq[i], A.rowptr_pq[i + 1], c4, A.bias_pq);
+        const bool lp = i < A.n_self_loop;
+        float4 o = gat_row(A.Yp, A.ldyp, A.Yp + 7 * h, ad, A.col_pq, A.rowptr_pq[i], A.rowptr_pq[i + 1], c4, A.bias_pq,
+                           A.n_self_loop > 0 ? i : -1, lp ? i : -1);
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         *reinterpret_cast<float4*>(A.out_q + i * A.ld_outq + c4) = o;
         return;
     }
     const long i = t;                                           // ---- product target
     const float* yi = A.Yp + i * A.ldyp;
-    const float4 t1 = gat_row(A.Yq, A.ldyq, A.Yq + h, yi[7 * h + 1], A.col_qp, A.rowptr_qp[i], A.rowptr_qp[i + 1], c4, A.bias_qp);
+    const float4 t1 = gat_row(A.Yq, A.ldyq, A.Yq + h, yi[7 * h + 1], A.col_qp, A.rowptr_qp[i], A.rowptr_qp[i + 1], c4, A.bias_qp,
+                              A.n_self_loop > 0 ? i : -1, i < A.n_self_loop ? i : -1);
     float4 gr = *reinterpret_cast<const float4*>(A.b_ih + c4);
     float4 gz = *reinterpret_cast<const float4*>(A.b_ih + h + c4);
     float4 gn = *reinterpret_cast<const float4*>(A.b_ih + 2 * h + c4);

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .sessions import ASIN_NUM, EDGE_PP, EDGE_PQ, EDGE_QP, MAX_SEQ_LEN, QUERY_VOCAB
+from .sessions import ASIN_NUM, EDGE_PP, EDGE_PQ, EDGE_QP, MAX_SEQ_LEN, QUERY_VOCAB, ActionTable
 
 ALPHA_PAD = 32          # extra output columns of the fused node transforms (2 used: alpha_src, alpha_dst)
 
@@ -235,12 +235,12 @@ class SessionEncoder:
         _lib.check(rc, "sss_linear")
         return out
 
-    def _gat(self, xs, a_src, a_dst, csr, n_dst, bias, relu, out):
+    def _gat(self, xs, a_src, a_dst, csr, n_dst, bias, relu, out, n_self_loop=0):
         rowptr, col, _ = csr
         rc = _lib.lib().sss_gat_aggregate(xs.data_ptr(), xs.stride(0), a_src.data_ptr(), a_src.stride(0),
                                           a_dst.data_ptr(), a_dst.stride(0), rowptr.data_ptr(), col.data_ptr(),
-                                          n_dst, self.cfg.h, bias.data_ptr(), relu, out.data_ptr(), out.stride(0),
-                                          self._st())
+                                          n_dst, self.cfg.h, bias.data_ptr(), relu, n_self_loop, out.data_ptr(),
+                                          out.stride(0), self._st())
         _lib.check(rc, "sss_gat_aggregate")
 
     # ------------------------------------------------------------------ batch preparation
@@ -254,6 +254,8 @@ class SessionEncoder:
         ``Batch.from_data_list`` on the host, outside the model's forward.)"""
         if isinstance(data, PreparedBatch):
             return data
+        if isinstance(data, ActionTable):
+            return self.prepare_actions(data)
         cfg, L, dev = self.cfg, _lib.lib(), self.device
         q, p = data["query"], data["product"]
         pb = PreparedBatch()
@@ -266,10 +268,11 @@ class SessionEncoder:
         pb.q_ids = None if pb.q_feat is not None else q.x.to(dev, torch.int64).contiguous()
         pb.p_ids = None if pb.p_feat is not None else p.x.to(dev, torch.int64).contiguous()
         ei = data.edge_index_dict
-        loops = cfg.self_loop_rule == "pyg_bipartite_global"
+        # the PyG self-loop rewrite is applied inside the aggregation kernels (n_self_loop)
+        pb.n_self_loop = min(pb.Nq, pb.Np) if cfg.self_loop_rule == "pyg_bipartite_global" else 0
         ei_qp, ei_pq, ei_pp = (ei[k].to(dev, torch.int64) for k in (EDGE_QP, EDGE_PQ, EDGE_PP))
-        pb.csr_qp = build_csr(ei_qp, pb.Np, pb.Nq, loops)          # targets = products
-        pb.csr_pq = build_csr(ei_pq, pb.Nq, pb.Np, loops)          # targets = queries
+        pb.csr_qp = build_csr(ei_qp, pb.Np, pb.Nq, False)          # targets = products
+        pb.csr_pq = build_csr(ei_pq, pb.Nq, pb.Np, False)          # targets = queries
         ew = None
         if self.use_edge_weight:
             ew = data.edge_weight_dict[EDGE_PP].to(dev, torch.float32)
@@ -289,6 +292,66 @@ class SessionEncoder:
         pb.qptr = torch.empty(pb.B + 1, dtype=torch.int32, device=dev)
         _lib.check(L.sss_segment_ptr(click_batch.data_ptr(), pb.n_clicks, pb.B, pb.pptr.data_ptr(), self._st()), "sss_segment_ptr")
         _lib.check(L.sss_segment_ptr(pb.q_batch.data_ptr(), pb.Nq, pb.B, pb.qptr.data_ptr(), self._st()), "sss_segment_ptr")
+        return pb
+
+    @torch.no_grad()
+    def prepare_actions(self, actions):
+        """Native graph construction (``csrc/graphbuild.hip``): a flat action table -- sessions
+        stored contiguously: ``sess_ptr``, per action ``is_search`` / ``item_id`` / ``query_tok``
+        (the CSV schema of the reference's decompose_data.py:13,30,42) -- becomes the prepared
+        batch entirely on the device: what ``sequence_to_graph`` + ``Batch.from_data_list`` do on
+        the host in the reference (util_amazon_filtered.py:98-230, test_amazon_filterd.py:485-488),
+        followed by the CSR-by-target conversion.  Two kernel sweeps + one 5-integer read-back
+        (the totals that size the outputs).  ``actions`` is an ``ActionTable`` (numpy) or an
+        object with the same four attributes as device tensors."""
+        cfg, L, dev = self.cfg, _lib.lib(), self.device
+        st = self._st()
+
+        def up(a, dtype):
+            t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+            return t.to(dev, dtype).contiguous()
+        sess_ptr = up(actions.sess_ptr, torch.int64)
+        is_search = up(actions.is_search, torch.uint8)
+        item_id = up(actions.item_id, torch.int64)
+        query_tok = up(actions.query_tok, torch.int64)
+        S_ = int(sess_ptr.shape[0] - 1)
+        if S_ <= 0:
+            raise _lib.SssError("prepare_actions: empty action table")
+        bases = torch.empty((5, S_ + 1), dtype=torch.int32, device=dev)
+        scratch = torch.empty(int(L.sss_graph_scratch_ints(S_)), dtype=torch.int32, device=dev)
+        err = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.check(L.sss_graph_counts(sess_ptr.data_ptr(), is_search.data_ptr(), item_id.data_ptr(), S_, bases.data_ptr(),
+                                      scratch.data_ptr(), err.data_ptr(), st), "sss_graph_counts")
+        tot = torch.cat([bases[:, S_], err]).tolist()              # the one host read-back of the build
+        Nq, Np, Xp, E, Epp, bad = (int(v) for v in tot)
+        if bad:
+            raise _lib.SssError("prepare_actions: a session has more than 64 actions")
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+        i64 = lambda n: torch.empty(n, dtype=torch.int64, device=dev)
+        pb = PreparedBatch()
+        pb.Nq, pb.Np, pb.B, pb.n_clicks = Nq, Np, S_, Xp
+        pb.q_ids, pb.q_batch, pb.q_pos = i64(Nq), i64(Nq), i32(Nq)
+        pb.p_ids, pb.p_batch, pb.p_cnt = i64(Np), i64(Np), i64(Np)
+        pb.q_feat = pb.p_feat = None
+        rp_qp, c_qp, rp_pq, c_pq = i32(Np + 1), i32(E), i32(Nq + 1), i32(E)
+        rp_pp, c_pp = i32(Np + 1), i32(Epp)
+        w_pp = torch.empty(Epp, dtype=torch.float32, device=dev)
+        pb.src_row, pb.pos_id = i32(Xp + Nq), i32(Xp + Nq)
+        out = _lib.GraphOut(q_x=pb.q_ids.data_ptr(), q_batch=pb.q_batch.data_ptr(), q_pos=pb.q_pos.data_ptr(),
+                            p_x=pb.p_ids.data_ptr(), p_batch=pb.p_batch.data_ptr(), p_cnt=pb.p_cnt.data_ptr(),
+                            rowptr_qp=rp_qp.data_ptr(), col_qp=c_qp.data_ptr(), rowptr_pq=rp_pq.data_ptr(),
+                            col_pq=c_pq.data_ptr(), rowptr_pp=rp_pp.data_ptr(), col_pp=c_pp.data_ptr(),
+                            w_pp=w_pp.data_ptr(), src_row=pb.src_row.data_ptr(), pos_id=pb.pos_id.data_ptr())
+        _lib.check(L.sss_graph_fill(sess_ptr.data_ptr(), is_search.data_ptr(), item_id.data_ptr(), query_tok.data_ptr(), S_,
+                                    bases.data_ptr(), ctypes.byref(out), st), "sss_graph_fill")
+        pb.csr_qp = (rp_qp, c_qp, None)
+        pb.csr_pq = (rp_pq, c_pq, None)
+        pb.csr_pp = (rp_pp, c_pp, w_pp if self.use_edge_weight else None)
+        pb.w_pp = w_pp
+        pb.qptr, pb.p_ptr, pb.pptr = bases[0], bases[1], bases[2]       # per-graph pointers come out of the scans
+        pb.n_self_loop = min(Nq, Np) if cfg.self_loop_rule == "pyg_bipartite_global" else 0
+        if Xp + Nq and (int(pb.pos_id.max().item()) >= cfg.max_seq_len):
+            raise IndexError("index out of range in self")      # what nn.Embedding raises upstream
         return pb
 
     def _features(self, ids, feat, table, n, buf=None):
@@ -371,7 +434,8 @@ class SessionEncoder:
                                 bias_qp=lw["bias_qp"].data_ptr(), b_ih=lw["b_ih"].data_ptr(),
                                 xin_p=xin_p.data_ptr(), ld_xin=NP.stride(0), out_p=out_p.data_ptr(), ld_out_p=NP.stride(0),
                                 np=pb.Np, rowptr_pq=rp_pq.data_ptr(), col_pq=c_pq.data_ptr(),
-                                bias_pq=lw["bias_pq"].data_ptr(), out_q=out_q.data_ptr(), ld_out_q=NQ.stride(0), nq=pb.Nq)
+                                bias_pq=lw["bias_pq"].data_ptr(), out_q=out_q.data_ptr(), ld_out_q=NQ.stride(0), nq=pb.Nq,
+                                n_self_loop=pb.n_self_loop)
             steps.append(("lin", arr, 2, din))
             steps.append(("layer", la))
             keep += [arr, la]
@@ -462,7 +526,7 @@ class SessionEncoder:
             self._linear(xin_p, lw["wp"], lw["bp"], Np, mp, din, Yp)
             self._linear(xin_q, lw["wq"], None, Nq, mq, din, Yq)
             # products <- queries (GAT) ; products <- products (GGC) ; GRU + sum + relu
-            self._gat(Yq[:, :h], Yq[:, h], Yp[:, 5 * h + 1], csr_qp, Np, lw["bias_qp"], 0, T1)
+            self._gat(Yq[:, :h], Yq[:, h], Yp[:, 5 * h + 1], csr_qp, Np, lw["bias_qp"], 0, T1, pb.n_self_loop)
             rowptr, col, wv = csr_pp
             rc = L.sss_csr_weighted_sum(Yp[:, h:2 * h].data_ptr(), Yp.stride(0), rowptr.data_ptr(), col.data_ptr(),
                                         0 if wv is None else wv.data_ptr(), Np, h, T2.data_ptr(), T2.stride(0),
@@ -474,7 +538,7 @@ class SessionEncoder:
                                    out_p.data_ptr(), NP.stride(0), self._st())
             _lib.check(rc, "sss_gru_combine")
             # queries <- products (GAT) + relu
-            self._gat(Yp[:, :h], Yp[:, 5 * h], Yq[:, h + 1], csr_pq, Nq, lw["bias_pq"], 1, out_q)
+            self._gat(Yp[:, :h], Yp[:, 5 * h], Yq[:, h + 1], csr_pq, Nq, lw["bias_pq"], 1, out_q, pb.n_self_loop)
         if self.debug_nan_checks and (torch.isnan(NQ).any() or torch.isnan(NP).any()):
             raise RuntimeError("nan in node embedding")
 

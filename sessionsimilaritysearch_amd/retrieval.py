@@ -33,6 +33,20 @@ class SessionItems:
         return int(self.ptr.shape[0] - 1)
 
     @classmethod
+    def from_prepared(cls, pbs, id_offset: int = 0):
+        """From natively built ``PreparedBatch``es (``SessionEncoder.prepare_actions``), in index
+        order: the graph -> product-node pointer and the item ids are already on the device."""
+        pbs = pbs if isinstance(pbs, (list, tuple)) else [pbs]
+        ptrs, items, base = [], [], 0
+        for pb in pbs:
+            p = pb.p_ptr.to(torch.int64)
+            ptrs.append(p[:-1] + base)
+            items.append(pb.p_ids.to(torch.int32))
+            base += int(pb.Np)
+        ptr = torch.cat(ptrs + [torch.tensor([base], dtype=torch.int64, device=ptrs[0].device)])
+        return cls(ptr.contiguous(), torch.cat(items).contiguous(), id_offset)
+
+    @classmethod
     def from_batch(cls, batch, device, id_offset: int = 0):
         """From a ``SessionBatch`` (or several, concatenated in index order): product nodes are
         already grouped by graph, in node order = the order of ``product.x``."""

@@ -76,12 +76,15 @@ def test_gat_aggregate_matches_oracle(cuda):
         xs_l = (xs @ ls.T).to(cuda).contiguous()
         al_s = ((xs @ ls.T) * a_s).sum(-1).to(cuda).contiguous()
         al_d = ((xd @ ld.T) * a_d).sum(-1).to(cuda).contiguous()
-        rowptr, col, _ = build_csr(ei.to(cuda), nd, ns, loops)
-        out = torch.empty((nd, h), device=cuda)
-        rc = _lib.lib().sss_gat_aggregate(xs_l.data_ptr(), h, al_s.data_ptr(), 1, al_d.data_ptr(), 1, rowptr.data_ptr(),
-                                          col.data_ptr(), nd, h, b.to(cuda).data_ptr(), 0, out.data_ptr(), h, _st(cuda))
-        _lib.check(rc, "gat")
-        assert (out.cpu().double() - ref).abs().max() < 2e-5
+        # the rewrite either materialised in the CSR, or applied on the fly by the kernel
+        for csr_loops, n_loop in ((loops, 0), (False, min(ns, nd) if loops else 0)):
+            rowptr, col, _ = build_csr(ei.to(cuda), nd, ns, csr_loops)
+            out = torch.empty((nd, h), device=cuda)
+            rc = _lib.lib().sss_gat_aggregate(xs_l.data_ptr(), h, al_s.data_ptr(), 1, al_d.data_ptr(), 1, rowptr.data_ptr(),
+                                              col.data_ptr(), nd, h, b.to(cuda).data_ptr(), 0, n_loop, out.data_ptr(), h,
+                                              _st(cuda))
+            _lib.check(rc, "gat")
+            assert (out.cpu().double() - ref).abs().max() < 2e-5
 
 
 def test_csr_sum_and_gru_match_torch(cuda):
@@ -319,3 +322,54 @@ def test_encoder_matches_independent_float64_fixture(cuda, loops, tag):
     assert np.abs(out.cpu().numpy() - z["out_" + tag]).max() < TOL
     assert np.abs(nodes["query"].cpu().numpy() - z["node_q_" + tag]).max() < TOL
     assert np.abs(nodes["product"].cpu().numpy() - z["node_p_" + tag]).max() < TOL
+
+
+# ---------------------------------------------------------------------------- native graph builder
+@pytest.mark.parametrize("seed,n,vocab", [(0, 1, 50), (1, 7, 50), (2, 300, 50), (3, 2500, 391572), (4, 33000, 391572)])
+@pytest.mark.parametrize("loops", [False, True])
+def test_native_graph_builder_is_bit_exact(cuda, seed, n, vocab, loops):
+    """csrc/graphbuild.hip (action table -> CSR batch on device) against the host builder +
+    torch CSR conversion it replaces -- itself checked against oracle/graph_ref.py on CPU --
+    array by array, and through the encoder."""
+    cfg = EncoderConfig(d_in=32, h=32, n_layers=1, d_out=64, n_items=vocab, n_query=33,
+                        self_loop_rule="pyg_bipartite_global" if loops else "none")
+    enc = SessionEncoder(cfg, init_weights(cfg, 5, tables=vocab < 1000), cuda, use_edge_weight=True)
+    acts = S.synthetic_actions(n, seed, vocab, 33)
+    ref = enc.prepare(S.build_batch(acts).to(cuda))
+    got = enc.prepare_actions(acts)
+    assert (got.Nq, got.Np, got.B, got.n_clicks) == (ref.Nq, ref.Np, ref.B, ref.n_clicks)
+    eq = lambda a, b: torch.equal(a.to(torch.int64), b.to(torch.int64))
+    assert eq(got.q_ids, ref.q_ids) and eq(got.p_ids, ref.p_ids)
+    assert eq(got.q_batch, ref.q_batch) and eq(got.p_batch, ref.p_batch)
+    for name in ("csr_qp", "csr_pq", "csr_pp"):
+        assert eq(getattr(got, name)[0], getattr(ref, name)[0]), name + ".rowptr"
+        assert eq(getattr(got, name)[1], getattr(ref, name)[1]), name + ".col"
+    assert torch.equal(got.csr_pp[2], ref.csr_pp[2])
+    assert eq(got.src_row, ref.src_row) and eq(got.pos_id, ref.pos_id)
+    assert eq(got.pptr, ref.pptr) and eq(got.qptr, ref.qptr) and got.n_self_loop == ref.n_self_loop
+    if vocab < 1000:
+        assert torch.equal(enc(got), enc(ref))
+
+
+def test_native_graph_builder_edge_cases(cuda):
+    """Search-only sessions (the "unknown item" node), repeated items, self transitions, a session
+    of 64 actions, and the > 64 actions error."""
+    cfg = EncoderConfig(d_in=32, h=32, n_layers=1, d_out=96, n_items=300, n_query=33, max_seq_len=65)
+    enc = SessionEncoder(cfg, init_weights(cfg, 7), cuda)
+    rng = np.random.default_rng(0)
+    long_srch = rng.random(64) < 0.3
+    ptr = np.array([0, 2, 3, 8, 10, 74])
+    srch = np.r_[np.array([1, 1, 0, 0, 1, 0, 0, 0, 1, 1], bool), long_srch]
+    item = np.r_[np.array([0, 0, 7, 7, 0, 9, 7, 7, 0, 0]), np.where(long_srch, 0, rng.integers(1, 6, 64))]
+    tok = np.r_[np.array([3, 4, 0, 0, 2, 0, 0, 0, 5, 6]), np.where(long_srch, rng.integers(1, 33, 64), 0)]
+    acts = S.ActionTable(ptr, srch, item, tok)
+    ref = enc.prepare(S.build_batch(acts).to(cuda))
+    got = enc.prepare_actions(acts)
+    eq = lambda a, b: torch.equal(a.to(torch.int64), b.to(torch.int64))
+    for name in ("csr_qp", "csr_pq", "csr_pp"):
+        assert eq(getattr(got, name)[0], getattr(ref, name)[0]) and eq(getattr(got, name)[1], getattr(ref, name)[1]), name
+    assert eq(got.src_row, ref.src_row) and eq(got.pos_id, ref.pos_id) and eq(got.p_ids, ref.p_ids) and eq(got.q_ids, ref.q_ids)
+    assert torch.equal(enc(got), enc(ref))
+    too_long = S.ActionTable(np.array([0, 65]), np.zeros(65, bool), np.arange(1, 66), np.zeros(65, np.int64))
+    with pytest.raises(_lib.SssError):
+        enc.prepare_actions(too_long)
