@@ -219,6 +219,25 @@ int sss_graph_fill(const int64_t* sess_ptr, const uint8_t* is_search, const int6
                    const int64_t* query_tok, int64_t n_sessions, const int32_t* bases,
                    const sss_graph_out* out, void* stream);
 
+/* ---- binary-code (Hamming) index: the reference's compressed variant -- sign bits of the
+ * BinarizeHead output (model/model.py:105-138), np.packbits((emb + 1) / 2),
+ * faiss.IndexBinaryFlat(nbits).add / .search (fine_tune_ours.py:839-843,871-876).
+ * sss_pack_sign_bits: x [n, c] fp32 (row stride ldx) -> out [n, nbytes] uint8, bit = ((int)((x+1)/2) != 0),
+ *   first column in the most significant bit of byte 0, zero padded (numpy packbits).
+ * sss_hamming_topk: q [nq, nbytes], codes [n, nbytes] uint8, nbytes in {16, 32, 64}; D_out [nq, k]
+ *   int32 Hamming distances ascending, I_out [nq, k] int64 ids ordered by (distance asc, id asc),
+ *   -1 / INT_MAX padded; status 0 = proven exact, 1 = re-run through the exhaustive entry point.
+ *   k <= 16 * splits (typically 1024); returns -1 for larger k (use the exhaustive entry point). */
+int sss_pack_sign_bits(const float* x, int64_t n, int c, int64_t ldx, uint8_t* out, int nbytes, void* stream);
+size_t sss_hamming_topk_workspace_bytes(int64_t nq, int64_t n);
+int sss_hamming_topk(const uint8_t* q, int64_t nq, const uint8_t* codes, int64_t n, int nbytes, int k,
+                     int64_t id_offset, int32_t* D_out, int64_t* I_out, int32_t* status, void* workspace,
+                     size_t workspace_bytes, void* stream);
+size_t sss_hamming_topk_exhaustive_workspace_bytes(int64_t nsel, int64_t n);
+int sss_hamming_topk_exhaustive(const uint8_t* q, const int32_t* qsel, int64_t nsel, const uint8_t* codes,
+                                int64_t n, int nbytes, int k, int64_t id_offset, int32_t* D_out,
+                                int64_t* I_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- neighbour-weighted item vote: get_prediction_by_knn after the search
  * (test_amazon_filterd.py:59-78; config C3's "aggregated top-10").  D [nq, s] fp32 and I [nq, s]
  * int64 are a search result (I < 0 = padding, skipped); session i's distinct items are

@@ -234,3 +234,26 @@ def recall_at_k(I_got, I_ref, k):
     """Mean overlap of returned ids with the oracle's exact top-k (recall@k of BASELINE.json)."""
     hits = [len(set(a[:k].tolist()) & set(b[:k].tolist())) for a, b in zip(I_got, I_ref)]
     return float(np.mean(hits)) / k
+
+
+# ------------------------------------------------------------------------- binary codes (Hamming)
+def pack_sign_bits(emb):
+    """The reference's packing of BinarizeHead outputs (fine_tune_ours.py:839-840):
+    ``np.packbits(((emb + 1) / 2).astype(int), axis=1)``."""
+    return np.packbits(((np.asarray(emb) + 1) / 2).astype(int), axis=1)
+
+
+def hamming_search(q_codes, codes, k, id_offset=0):
+    """``faiss.IndexBinaryFlat.search`` (Appendix A.5): Hamming distance ascending, int32 D; ties by
+    ascending id (the build's rule); -1 / INT_MAX padding."""
+    q_codes, codes = np.asarray(q_codes, np.uint8), np.asarray(codes, np.uint8)
+    lut = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    nq, n = q_codes.shape[0], codes.shape[0]
+    D = np.full((nq, k), 0x7fffffff, np.int32)
+    I = np.full((nq, k), -1, np.int64)
+    for a in range(nq):
+        dist = lut[np.bitwise_xor(codes, q_codes[a][None, :])].sum(axis=1).astype(np.int64)
+        order = np.lexsort((np.arange(n), dist))[:k]
+        D[a, :order.size] = dist[order]
+        I[a, :order.size] = order + id_offset
+    return D, I

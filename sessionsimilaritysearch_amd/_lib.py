@@ -48,6 +48,13 @@ _SIGNATURES = {
     "sss_segment_pool": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p,
                                  c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "sss_segment_ptr": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "sss_pack_sign_bits": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p]),
+    "sss_hamming_topk_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sss_hamming_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_size_t, c_void_p]),
+    "sss_hamming_topk_exhaustive_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sss_hamming_topk_exhaustive": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64,
+                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sss_graph_scratch_ints": (c_size_t, [c_int64]),
     "sss_graph_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sss_graph_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

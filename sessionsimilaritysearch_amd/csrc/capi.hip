@@ -70,6 +70,12 @@ int pool_expand_mean(const float*, const float*, long, const int*, const int*, c
 int pool_attention(const float*, long, const float*, long, const float*, long, const float*, const int*, const int*, long, long,
                    int, int, float, float*, long, hipStream_t);
 int item_vote(const float*, const long*, long, int, const long*, const int*, long, long, int, long*, double*, int*, hipStream_t);
+size_t hamming_workspace_bytes(long nq, long n);
+int hamming_topk(const unsigned char*, long, const unsigned char*, long, int, int, long, int*, long*, int*, void*, size_t, hipStream_t);
+size_t hamming_exhaustive_workspace_bytes(long nsel, long n);
+int hamming_topk_exhaustive(const unsigned char*, const int*, long, const unsigned char*, long, int, int, long, int*, long*, void*,
+                            size_t, hipStream_t);
+int pack_sign_bits(const float*, long, int, long, unsigned char*, int, hipStream_t);
 struct GraphOut {
     long* q_x; long* q_batch; int* q_pos; long* p_x; long* p_batch; long* p_cnt;
     int* rowptr_qp; int* col_qp; int* rowptr_pq; int* col_pq; int* rowptr_pp; int* col_pp; float* w_pp;
@@ -193,6 +199,24 @@ int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64
                        int d, int normalize, float eps, float* out, int64_t ld_out, void* stream) {
     return sss::pool_attention(node, ld_node, a, ld_a, b, ld_b, watt, pptr, qptr, n_clicks, n_graphs, d, normalize, eps, out,
                                ld_out, ST(stream));
+}
+int sss_pack_sign_bits(const float* x, int64_t n, int c, int64_t ldx, uint8_t* out, int nbytes, void* stream) {
+    return sss::pack_sign_bits(x, n, c, ldx, out, nbytes, ST(stream));
+}
+size_t sss_hamming_topk_workspace_bytes(int64_t nq, int64_t n) { return sss::hamming_workspace_bytes(nq, n); }
+int sss_hamming_topk(const uint8_t* q, int64_t nq, const uint8_t* codes, int64_t n, int nbytes, int k, int64_t id_offset,
+                     int32_t* D_out, int64_t* I_out, int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+    return sss::hamming_topk(q, nq, codes, n, nbytes, k, id_offset, D_out, reinterpret_cast<long*>(I_out), status, workspace,
+                             workspace_bytes, ST(stream));
+}
+size_t sss_hamming_topk_exhaustive_workspace_bytes(int64_t nsel, int64_t n) {
+    return sss::hamming_exhaustive_workspace_bytes(nsel, n);
+}
+int sss_hamming_topk_exhaustive(const uint8_t* q, const int32_t* qsel, int64_t nsel, const uint8_t* codes, int64_t n,
+                                int nbytes, int k, int64_t id_offset, int32_t* D_out, int64_t* I_out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    return sss::hamming_topk_exhaustive(q, qsel, nsel, codes, n, nbytes, k, id_offset, D_out, reinterpret_cast<long*>(I_out),
+                                        workspace, workspace_bytes, ST(stream));
 }
 size_t sss_graph_scratch_ints(int64_t n_sessions) { return sss::graph_scratch_ints(n_sessions); }
 int sss_graph_counts(const int64_t* sess_ptr, const uint8_t* is_search, const int64_t* item_id, int64_t n_sessions,

@@ -273,3 +273,98 @@ def build_index(emb, metric: str, device=None) -> FlatIndex:
     else:
         raise RuntimeError("Unregnozed metric", metric)
     return index
+
+
+# ------------------------------------------------------------------------------- binary codes
+def pack_sign_bits(emb, code_bytes: int | None = None) -> torch.Tensor:
+    """``np.packbits(((emb + 1) / 2).astype(int), axis=1)`` of the reference (fine_tune_ours.py:839-840,
+    871-872) on the device: ``emb`` is the (+-1 valued) BinarizeHead output [n, c]; returns uint8
+    [n, code_bytes] (default ceil(c / 8), zero padded like packbits)."""
+    dev = _dev() if isinstance(emb, np.ndarray) or not emb.is_cuda else emb.device
+    x = _as_device_f32(emb, dev)
+    n, c = x.shape
+    nbytes = (c + 7) // 8 if code_bytes is None else int(code_bytes)
+    out = torch.empty((n, nbytes), dtype=torch.uint8, device=dev)
+    rc = _lib.lib().sss_pack_sign_bits(x.data_ptr(), n, c, x.stride(0), out.data_ptr(), nbytes, _lib.stream_ptr(dev))
+    _lib.check(rc, "sss_pack_sign_bits")
+    return out
+
+
+class BinaryFlatIndex:
+    """``faiss.IndexBinaryFlat(nbits)`` as the reference uses it (fine_tune_ours.py:841-843,876):
+    ``add(codes)`` with uint8 [n, nbits / 8] rows, ``search(codes, k) -> (D int32, I int64)`` by
+    Hamming distance ascending, ties by ascending id.  Codes of 128 / 256 / 512 bits run on the
+    fused scan; other widths (and unproven queries) go through the exhaustive kernels after the
+    codes are zero padded to the next supported width (padding adds no distance)."""
+
+    WIDTHS = (16, 32, 64)
+
+    def __init__(self, nbits: int, device=None):
+        if nbits % 8:
+            raise ValueError("nbits must be a multiple of 8")
+        self.d = int(nbits)
+        self.code_bytes = nbits // 8
+        if self.code_bytes > 64:
+            raise ValueError("codes longer than 512 bits are not supported")
+        self._w = next(w for w in self.WIDTHS if w >= self.code_bytes)     # stored (padded) row bytes
+        self.device = _dev(device)
+        self._codes = torch.empty((0, self._w), dtype=torch.uint8, device=self.device)
+        self._ws = None
+        self.id_offset = 0
+        self.last_fallback_queries = 0
+
+    @property
+    def ntotal(self) -> int:
+        return int(self._codes.shape[0])
+
+    def _rows(self, x):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint8))
+        x = x.to(self.device, torch.uint8)
+        if x.dim() != 2 or x.shape[1] != self.code_bytes:
+            raise ValueError(f"expected uint8 [n, {self.code_bytes}], got {tuple(x.shape)}")
+        if self._w != self.code_bytes:
+            pad = torch.zeros((x.shape[0], self._w), dtype=torch.uint8, device=self.device)
+            pad[:, :self.code_bytes] = x
+            x = pad
+        return x.contiguous()
+
+    def add(self, codes):
+        self._codes = torch.cat([self._codes, self._rows(codes)], dim=0)
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def search(self, codes, k: int):
+        is_np = isinstance(codes, np.ndarray)
+        L = _lib.lib()
+        q = self._rows(codes)
+        nq, n, k = q.shape[0], self.ntotal, int(k)
+        D = torch.full((nq, k), 0x7fffffff, dtype=torch.int32, device=self.device)
+        I = torch.full((nq, k), -1, dtype=torch.int64, device=self.device)
+        self.last_fallback_queries = 0
+        if nq and n:
+            st = _lib.stream_ptr(self.device)
+            bad = None
+            ws = self._workspace(L.sss_hamming_topk_workspace_bytes(nq, n))
+            status = torch.empty((nq,), dtype=torch.int32, device=self.device)
+            rc = L.sss_hamming_topk(q.data_ptr(), nq, self._codes.data_ptr(), n, self._w, k, self.id_offset, D.data_ptr(),
+                                    I.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), st)
+            if rc == 0:
+                bad = torch.nonzero(status).flatten().to(torch.int32)
+            else:                               # k beyond the fused capacity: everything through the exhaustive path
+                bad = torch.arange(nq, dtype=torch.int32, device=self.device)
+            self.last_fallback_queries = int(bad.numel())
+            per = max(1, min(65535, _EXHAUSTIVE_WS_BYTES // max(1, 2 * n)))
+            for lo in range(0, bad.numel(), per):
+                sel = bad[lo:lo + per].contiguous()
+                ws = self._workspace(L.sss_hamming_topk_exhaustive_workspace_bytes(sel.numel(), n))
+                rc = L.sss_hamming_topk_exhaustive(q.data_ptr(), sel.data_ptr(), sel.numel(), self._codes.data_ptr(), n,
+                                                   self._w, k, self.id_offset, D.data_ptr(), I.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), st)
+                _lib.check(rc, "sss_hamming_topk_exhaustive")
+        if is_np:
+            return D.cpu().numpy(), I.cpu().numpy()
+        return D, I

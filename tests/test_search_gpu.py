@@ -369,3 +369,48 @@ def test_index_add_in_pieces_equals_single_add(cuda):
     Da, Ia = a.search(q, 10)
     Db, Ib = b.search(q, 10)
     assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)
+
+
+# ----------------------------------------------------------------------------------------------
+# Binary-code index (fine_tune_ours.py:839-843,871-876): packed sign bits + Hamming top-k.
+def test_pack_sign_bits_matches_numpy_packbits(cuda):
+    from sessionsimilaritysearch_amd.index import pack_sign_bits
+    rng = np.random.default_rng(60)
+    for c in (250, 256, 13, 512):                                   # the reference's code_len is 250 (config.py:4)
+        emb = np.sign(rng.standard_normal((77, c))).astype(np.float32)
+        emb[0, :5] = 0.0                                            # sign(0) = 0 -> (0 + 1) / 2 = 0.5 -> int 0
+        emb[1, :3] = [3.0, -3.0, 0.999]                             # non-sign inputs follow astype(int) + packbits too
+        got = pack_sign_bits(emb).cpu().numpy()
+        assert np.array_equal(got, sr.pack_sign_bits(emb))
+
+
+@pytest.mark.parametrize("nq,n,nbits,k", [(300, 20000, 256, 100), (64, 5000, 128, 10), (17, 3000, 512, 100),
+                                          (1024, 200000, 256, 100), (5, 40, 256, 100), (40, 9000, 250, 100)])
+def test_hamming_search_matches_oracle(cuda, nq, n, nbits, k):
+    from sessionsimilaritysearch_amd.index import BinaryFlatIndex, pack_sign_bits
+    rng = np.random.default_rng(61 + n)
+    base = np.sign(rng.standard_normal((n, nbits))).astype(np.float32)
+    qe = base[rng.integers(0, n, nq)].copy()
+    flip = rng.random(qe.shape) < 0.2                               # queries = noisy copies of corpus rows
+    qe[flip] *= -1
+    codes, qcodes = sr.pack_sign_bits(base), sr.pack_sign_bits(qe)
+    idx = BinaryFlatIndex(codes.shape[1] * 8, cuda)
+    idx.add(pack_sign_bits(base[: n // 2]))
+    idx.add(codes[n // 2:])                                         # device-packed and host-packed rows mix
+    D, I = idx.search(qcodes, k)
+    Dr, Ir = sr.hamming_search(qcodes, codes, k)
+    assert D.dtype == np.int32 and np.array_equal(D, Dr) and np.array_equal(I, Ir)
+
+
+def test_hamming_massive_ties(cuda):
+    """Few distinct codes -> thousands of rows tie at every distance; ids must come out ascending."""
+    from sessionsimilaritysearch_amd.index import BinaryFlatIndex
+    rng = np.random.default_rng(62)
+    protos = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+    codes = protos[rng.integers(0, 6, 50000)]
+    q = protos[:4]
+    idx = BinaryFlatIndex(256, cuda)
+    idx.add(codes)
+    D, I = idx.search(q, 100)
+    Dr, Ir = sr.hamming_search(q, codes, 100)
+    assert np.array_equal(D, Dr) and np.array_equal(I, Ir)
