@@ -63,6 +63,27 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def build_c3_corpus(enc, cfg, n_sessions, device):
+    """Config C3: every session contributes 4 prefix sub-sessions (25/50/75/100 % of its actions,
+    the deterministic stand-in for the reference's random cut, train_subsession_embedding.py:41).
+    Returns the normalised [4 * n_sessions, d] matrix (rows ordered block / prefix / session) and
+    the graph -> distinct-items CSR the neighbour vote reads (product.x of every indexed graph)."""
+    from sessionsimilaritysearch_amd.retrieval import SessionItems
+    out = torch.empty((4 * n_sessions, cfg.d_out), dtype=torch.float32, device=device)
+    pbs, row = [], 0
+    for b0 in range(0, n_sessions, BLOCK):
+        nb = min(BLOCK, n_sessions - b0)
+        acts = S.synthetic_actions(nb, 20260000 + 3 * 100000 + b0 // BLOCK, cfg.n_items, cfg.n_query)
+        for f in (1, 2, 3, 4):
+            pb = enc.prepare_actions(acts.prefix(f, 4))
+            out[row:row + nb] = enc(pb, l2_normalize=True)
+            keep = type("Items", (), {})()              # only what SessionItems needs (drop the big CSR buffers)
+            keep.p_ptr, keep.p_ids, keep.Np = pb.p_ptr.clone(), pb.p_ids, pb.Np
+            pbs.append(keep)
+            row += nb
+    return out, SessionItems.from_prepared(pbs)
+
+
 def build_corpus_shard(enc, cfg, n_total, lo, hi, device, source):
     """Normalised session vectors of rows [lo, hi) of the corpus, on device."""
     out = torch.empty((hi - lo, cfg.d_out), dtype=torch.float32, device=device)
@@ -81,9 +102,7 @@ def build_corpus_shard(enc, cfg, n_total, lo, hi, device, source):
         a, b = max(lo, b0), min(hi, b0 + nb)
         if a > b0 or b < b0 + nb:
             acts = acts.slice(a - b0, b - b0)
-        emb = enc(S.build_batch(acts).to(device))
-        out[a - lo:b - lo] = emb
-    normalize_(out)
+        out[a - lo:b - lo] = enc(enc.prepare_actions(acts), l2_normalize=True)     # native graph build + fused encoder
     return out
 
 
@@ -101,6 +120,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="index element type (bf16 + --d 256 --nq 4096 --corpus-source random = config C5)")
     ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--workload", choices=["search", "c3"], default="search",
+                    help="c3: 4 prefix sub-sessions per session indexed, top-500 neighbours -> item vote -> top-10 items (1 GPU)")
+    ap.add_argument("--sample-size", type=int, default=500)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,9 +151,18 @@ def main():
     enc = SessionEncoder(cfg, weights, device).eval()
 
     # ---- index build (not timed): this rank's rows of the corpus
+    c3 = args.workload == "c3"
+    if c3 and (world != 1 or args.dtype != "f32"):
+        raise SystemExit("--workload c3 is the single-GPU f32 configuration")
+    n_sessions = n_total
+    if c3:
+        n_total = 4 * n_sessions                # rows of the index
     lo, hi = shard_range(n_total, world, rank)
     t0 = time.time()
-    xb = build_corpus_shard(enc, cfg, n_total, lo, hi, device, args.corpus_source)
+    if c3:
+        xb, session_items = build_c3_corpus(enc, cfg, n_sessions, device)
+    else:
+        xb = build_corpus_shard(enc, cfg, n_total, lo, hi, device, args.corpus_source)
     torch.cuda.synchronize()
     log(rank, f"corpus shard rows [{lo},{hi}) built in {time.time() - t0:.1f}s")
     if args.dtype == "bf16":
@@ -143,8 +174,14 @@ def main():
 
     # ---- query batch, resident in HBM
     q_acts = S.synthetic_actions(nq, 20269999, cfg.n_items, cfg.n_query)
-    q_host = S.build_batch(q_acts)
-    qbatch = enc.prepare(q_host.to(device))      # batched CSR session graph, resident in HBM
+    if c3:
+        q_acts = q_acts.prefix(1, 2)             # the query is a prefix sub-session (test_amazon_filterd.py:546)
+    q_host = S.build_batch(q_acts)               # host copy: only the CPU baseline / oracle read it
+    qbatch = enc.prepare_actions(q_acts)         # batched CSR session graph built on device, resident in HBM
+    k_items = k
+    if c3:
+        from sessionsimilaritysearch_amd.retrieval import knn_item_vote
+        k = args.sample_size                     # neighbours searched; k_items items voted
 
     def embed():
         emb = enc(qbatch, l2_normalize=True)
@@ -152,11 +189,17 @@ def main():
 
     def step_async():
         emb = embed()
-        return (emb,) + tuple(sharded.search_async(emb, k))
+        res = (emb,) + tuple(sharded.search_async(emb, k))
+        if c3:
+            res = res + knn_item_vote(res[1], res[2], session_items, k_items)
+        return res
 
     def step_sync():
         emb = embed()
-        return (emb,) + tuple(sharded.search(emb, k)) + (None,)
+        res = (emb,) + tuple(sharded.search(emb, k)) + (None,)
+        if c3:
+            res = res + knn_item_vote(res[1], res[2], session_items, k_items)
+        return res
 
     def timed_region(step):
         for _ in range(args.warmup):
@@ -181,12 +224,14 @@ def main():
         return res, float(unp[1].item()), int(unp[0].item())
 
     api = "search_async + on-device unproven counter"
-    (emb, D, I, status), elapsed, unproven = timed_region(step_async)
+    res, elapsed, unproven = timed_region(step_async)
+    emb, D, I, status = res[:4]
     if unproven != 0:       # some query needed the exhaustive path: report the synchronous exact API instead
         tot_ms, launches = ctypes.c_double(0), ctypes.c_int(0)
         L.sss_profile_read(ctypes.byref(tot_ms), ctypes.byref(launches))
         api = "search (synchronous exact API; %d queries were unproven in the async run)" % unproven
-        (emb, D, I, status), elapsed, _ = timed_region(step_sync)
+        res, elapsed, _ = timed_region(step_sync)
+        emb, D, I, status = res[:4]
 
     tot_ms, launches = ctypes.c_double(0), ctypes.c_int(0)
     _lib.check(L.sss_profile_read(ctypes.byref(tot_ms), ctypes.byref(launches)), "profile_read")
@@ -205,10 +250,11 @@ def main():
         return e0.elapsed_time(e1) / n
     embed_ms = timed(embed)
     search_ms = timed(lambda: sharded.search_async(emb, k))
+    vote_ms = timed(lambda: knn_item_vote(D, I, session_items, k_items)) if c3 else None
 
     # ---- exactness: recall@10 / id equality against the oracle (canonical scores of the stored vectors)
     from oracle import search_ref as sr, gnn_ref       # checker + CPU baseline only
-    nrq = min(args.recall_queries, nq)
+    nrq = min(args.recall_queries, nq) if not c3 else min(8, nq)
     q_np = emb[:nrq].float().cpu().numpy()
     Dl, Il = sr.search_exact(q_np, xb.float().cpu().numpy(), k, id_offset=lo)
     if world > 1:
@@ -224,10 +270,17 @@ def main():
     recall = sr.recall_at_k(I_got, Ir, k)
     ids_exact = bool(np.array_equal(I_got, Ir))
     score_err = float(np.abs(D_got - Dr).max())
+    items_exact = None
+    if c3:      # aggregated top-10 items of the checked queries against the oracle's get_prediction_by_knn
+        ptr, its = session_items.ptr.cpu().numpy(), session_items.items.cpu().numpy()
+        lists = {int(s_): its[ptr[s_]:ptr[s_ + 1]] for s_ in np.unique(Ir[Ir >= 0])}
+        got_items = res[4][:nrq].cpu().numpy()
+        items_exact = all([int(v) for v in got_items[r] if v >= 0] == sr.knn_item_vote(Dr[r], Ir[r], lists, k_items)
+                          for r in range(nrq))
 
     # ---- CPU baseline (rank 0, N = 1): the reference path restated on the host cores
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not c3:
         # the GPU box gives one-GPU jobs a CPU share of ~16 cores whatever os.cpu_count() says;
         # more threads than that only thrash (measured: 256 threads -> 100x slower)
         cores = max(1, min(len(os.sched_getaffinity(0)), 16))
@@ -268,15 +321,21 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"{n_total}-session corpus d={d} ({args.corpus_source}), GNN embed (2-layer "
-                                   f"HeteroGGNN + positional-attention pooling + normalise) + cosine top-{k}, query batch {nq}; "
-                                   "query graphs prepared (CSR) before the timed region",
+            "config": {"workload": (f"{n_sessions}-session corpus x 4 prefix sub-sessions = {n_total} vectors d={d}, GNN embed + "
+                                    f"cosine top-{k} neighbours + neighbour item vote -> top-{k_items} items, query batch {nq}"
+                                    if c3 else
+                                    f"{n_total}-session corpus d={d} ({args.corpus_source}), GNN embed (2-layer "
+                                    f"HeteroGGNN + positional-attention pooling + normalise) + cosine top-{k}, query batch {nq}")
+                                   + "; query graphs prepared (CSR, on device) before the timed region",
                        "timed_api": api,
                        "corpus_rows": n_total, "rows_per_gpu": hi - lo, "d": d, "k": k, "query_batch": nq,
                        "parallelism": f"corpus row-sharded x{world}, 1 all-gather + merge" if world > 1 else "single GPU"},
             "recall_at_10": round(recall, 6), "ids_bit_exact": ids_exact, "max_score_err": score_err,
             "recall_queries_checked": nrq, "unproven_queries": unproven,
-            "stage_ms": {"embed_normalize": round(embed_ms, 4), "score_topk_merge": round(search_ms, 4)},
+            "stage_ms": {"embed_normalize": round(embed_ms, 4), "score_topk_merge": round(search_ms, 4),
+                         **({"item_vote": round(vote_ms, 4)} if c3 else {})},
+            **({"c3": {"sessions": n_sessions, "index_rows": n_total, "sample_size": k, "items_returned": k_items,
+                       "items_bit_exact": items_exact, "queries_checked": nrq}} if c3 else {}),
             "roofline": {"bound": "mfma", "kernel": f"k_scan<{d * (4 if args.dtype == 'f32' else 2)},*,{args.dtype}>",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,

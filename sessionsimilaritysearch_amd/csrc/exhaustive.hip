@@ -2,7 +2,7 @@
 // row, then an exact top-k.  This is the correctness backstop behind k_ip_topk_f32 (queries
 // whose fused result could not be proven exact, tiny corpora, k larger than the fused path,
 // the IndexFlatL2 metric of reference test_amazon_filterd.py:215-217, any d % 4 == 0 such as
-// the reference's D = 1600).  It favours simplicity over speed; DESIGN.md "exactness".
+// the reference's D = 1600).  O(n d) scoring + O(n) radix selection per query; DESIGN.md "exactness".
 #include "scan.h"
 
 namespace sss {
@@ -61,50 +61,119 @@ __global__ __launch_bounds__(64) void k_exact_scores(const void* __restrict__ Qv
     }
 }
 
-// One block per selected query: k rounds of "largest key strictly below the previous one"
-// over the n scores (keys are unique because ids are).  O(k*n) reads -- backstop only.
-constexpr int FULL_THREADS = 1024;
-__global__ __launch_bounds__(FULL_THREADS) void k_topk_full(const float* __restrict__ scores,
-                                                            const int* __restrict__ qsel, long n,
-                                                            int k, long id_offset, int metric,
-                                                            float* __restrict__ D_out,
-                                                            long* __restrict__ I_out) {
-    __shared__ unsigned long long wbest[FULL_THREADS / 64];
-    __shared__ unsigned long long s_prev;
+// One block per selected query: exact top-k of its n canonical scores in O(n):
+//   1. radix select (4 passes of 8 bits over the order-preserving uint of the score, LDS
+//      histograms) -> T = the k-th best score and how many rows tied at T are still needed;
+//   2. collect every row better than T (unordered) and, scanning ids in increasing order, the
+//      lowest-id rows equal to T;
+//   3. bitonic sort of the k collected (score desc, id asc) keys, write.
+// Correct for any amount of ties (mass duplicates, identical rows).
+constexpr int RS_THREADS = 1024;
+constexpr int RS_MAX_K = 1024;
+__global__ __launch_bounds__(RS_THREADS) void k_topk_radix(const float* __restrict__ scores,
+                                                           const int* __restrict__ qsel, long n, int k,
+                                                           long id_offset, int metric,
+                                                           float* __restrict__ D_out, long* __restrict__ I_out) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long keys[RS_MAX_K];
+    __shared__ unsigned s_prefix, s_need, s_count, s_wave[RS_THREADS / 64], s_taken;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float* s = scores + (size_t)f * n;
     const size_t out = (size_t)qsel[f] * k;
-    unsigned long long prev = ~0ull;
-    for (int it = 0; it < k; ++it) {
-        unsigned long long best = 0;
-        for (long i = tid; i < n; i += FULL_THREADS) {
-            const float v = metric == 0 ? s[i] : -s[i];
-            const unsigned long long key = make_key(v, (int)i);
-            if (key < prev && key > best) best = key;
+    auto key_of = [&](long i) { return f2ord(metric == 0 ? s[i] : -s[i]); };
+    const int kk = (long)k < n ? k : (int)n;            // rows actually returned
+    int K2 = 64;
+    while (K2 < kk) K2 <<= 1;
+    for (int i = tid; i < K2; i += RS_THREADS) keys[i] = 0ull;
+    unsigned T = 0, need = kk;
+    if (kk < n) {                                        // (kk == n: every row is returned, no selection needed)
+        unsigned prefix = 0, mask = 0;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            for (int i = tid; i < 256; i += RS_THREADS) hist[i] = 0;
+            __syncthreads();
+            for (long i = tid; i < n; i += RS_THREADS) {
+                const unsigned key = key_of(i);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned cum = 0;
+                int b = 255;
+                for (; b > 0; --b) {                     // best bucket first
+                    if (cum + hist[b] >= need) break;
+                    cum += hist[b];
+                }
+                s_prefix = prefix | ((unsigned)b << shift);
+                s_need = need - cum;                     // rank still to find inside the chosen bucket
+            }
+            __syncthreads();
+            prefix = s_prefix; need = s_need;
+            mask |= 255u << shift;
+            __syncthreads();
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(best, o);
-            best = other > best ? other : best;
-        }
-        if (lane == 0) wbest[wv] = best;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned long long g = 0;
-            for (int w = 0; w < FULL_THREADS / 64; ++w) g = wbest[w] > g ? wbest[w] : g;
-            s_prev = g;
-            if (g == 0) {
-                D_out[out + it] = metric == 0 ? -3.4028234663852886e38f : 3.4028234663852886e38f;
-                I_out[out + it] = -1;
-            } else {
-                const float v = key_score(g);
-                D_out[out + it] = metric == 0 ? v : -v;
-                I_out[out + it] = (long)key_id(g) + id_offset;
+        T = prefix;                                      // the kk-th best key; `need` rows equal to it are wanted
+    }
+    if (tid == 0) { s_count = 0; s_taken = 0; }
+    __syncthreads();
+    // ---- rows strictly better than T (fewer than kk of them), in any order
+    if (kk < n) {
+        for (long i = tid; i < n; i += RS_THREADS) {
+            const unsigned key = key_of(i);
+            if (key > T) {
+                const unsigned p = atomicAdd(&s_count, 1u);
+                keys[p] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)i);
             }
         }
+    }
+    __syncthreads();
+    // ---- rows equal to T (every row when kk == n), lowest ids first: chunks in id order + block prefix sum
+    const unsigned want = kk < n ? need : (unsigned)kk;
+    for (long base = 0; base < n; base += RS_THREADS) {
+        if (s_taken >= want) break;                      // uniform: s_taken only changes between barriers
+        const long i = base + tid;
+        unsigned key = 0;
+        bool hit = false;
+        if (i < n) { key = key_of(i); hit = kk < n ? key == T : true; }
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(hit);
+        if (lane == 0) s_wave[wv] = (unsigned)__builtin_popcountll(b);
         __syncthreads();
-        prev = s_prev;
-        if (prev == 0) prev = 0;   // exhausted: every later round also yields 0 -> padding
+        unsigned before = 0;
+        for (int w = 0; w < wv; ++w) before += s_wave[w];
+        const unsigned rank = s_taken + before + (unsigned)__builtin_popcountll(b & ((1ull << lane) - 1ull));
+        if (hit && rank < want) keys[s_count + rank] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)i);
+        __syncthreads();
+        if (tid == 0) {
+            unsigned tot = 0;
+            for (int w = 0; w < RS_THREADS / 64; ++w) tot += s_wave[w];
+            s_taken += tot;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- order by (score desc, id asc) == key descending; padding keys are 0
+    for (int kq = 2; kq <= K2; kq <<= 1) {
+        for (int j = kq >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < K2; i += RS_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys[i], bq = keys[ixj];
+                    const bool desc = (i & kq) == 0;
+                    if (desc ? a < bq : a > bq) { keys[i] = bq; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += RS_THREADS) {
+        if (i < kk) {
+            const float v = key_score(keys[i]);
+            D_out[out + i] = metric == 0 ? v : -v;
+            I_out[out + i] = (long)key_id(keys[i]) + id_offset;
+        } else {                                         // faiss pads missing results
+            D_out[out + i] = metric == 0 ? -3.4028234663852886e38f : 3.4028234663852886e38f;
+            I_out[out + i] = -1;
+        }
     }
 }
 
@@ -118,7 +187,7 @@ int ip_topk_exhaustive(const void* q, const int* qsel, long nsel, const void* c,
         set_error("ip_topk_exhaustive: need nsel, n, k > 0, d %% 4 == 0 (f32) / d %% 8 == 0 (bf16), metric in {0,1}");
         return SSS_EINVAL;
     }
-    if (n >= (1L << 31) || nsel > 65535) { set_error("ip_topk_exhaustive: n < 2^31, nsel <= 65535"); return SSS_EINVAL; }
+    if (n >= (1L << 31) || nsel > 65535 || k > RS_MAX_K) { set_error("ip_topk_exhaustive: n < 2^31, nsel <= 65535, k <= 1024"); return SSS_EINVAL; }
     if (ws_bytes < ip_topk_exhaustive_workspace_bytes(nsel, n)) {
         set_error("ip_topk_exhaustive: workspace too small");
         return SSS_EWORKSPACE;
@@ -132,8 +201,8 @@ int ip_topk_exhaustive(const void* q, const int* qsel, long nsel, const void* c,
         hipLaunchKernelGGL(k_exact_scores<DT_BF16>, dim3((unsigned)gx, (unsigned)nsel), dim3(64), 0, st, q, qsel, c, n, d, metric, scores);
     int rc = check_launch("k_exact_scores");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_topk_full, dim3((unsigned)nsel), dim3(FULL_THREADS), 0, st, scores, qsel, n, k, id_offset, metric, D_out, I_out);
-    return check_launch("k_topk_full");
+    hipLaunchKernelGGL(k_topk_radix, dim3((unsigned)nsel), dim3(RS_THREADS), 0, st, scores, qsel, n, k, id_offset, metric, D_out, I_out);
+    return check_launch("k_topk_radix");
 }
 
 }  // namespace sss
