@@ -152,7 +152,7 @@ typedef struct {
     const int64_t* ids; const float* table; float* xcopy; int64_t ld_xcopy;
     const float* w; int64_t ldw; const float* bias;
     float* y; int64_t ldy;
-    int64_t n; int32_t m; int32_t reserved;
+    int64_t n; int32_t m; int32_t act;      /* epilogue activation: 0 none, 1 relu, 2 tanh */
 } sss_linear_problem;
 int sss_linear_grouped(const sss_linear_problem* problems, int n_problems, int k, void* stream);
 
@@ -180,15 +180,30 @@ int sss_hetero_layer_update(const sss_layer_args* args, void* stream);
  * (model/gnn.py:193-217): expand_mean writes node[e] = tanh([lin[src_row[e]] ; pos_emb[pos_id[e]]])
  * and coarse[g] = mean over the graph's expanded rows; attention computes
  * out[g] = mean_e(node[e] * (watt . sigmoid(a[e] + b[g]))) and, if normalize != 0, applies the
- * reference normalize (util_amazon_filtered.py:28-31) to the row.  d = d_lin + p <= 256. */
+ * reference normalize (util_amazon_filtered.py:28-31) to the row; reduce_sum != 0 sums instead of
+ * averaging (the global_add_pool of SRGNN_Pooling, model/gnn.py:178).  d = d_lin + p <= 256. */
 int sss_pool_expand_mean(const float* lin_p, const float* lin_q, int64_t ld_lin, const int32_t* src_row,
                          const int32_t* pos_id, const int32_t* pptr, const int32_t* qptr, int64_t n_clicks,
                          int64_t n_graphs, int d_lin, int p, const float* pos_emb, float* node,
                          int64_t ld_node, float* coarse, int64_t ld_coarse, void* stream);
 int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64_t ld_a, const float* b,
                        int64_t ld_b, const float* watt, const int32_t* pptr, const int32_t* qptr,
-                       int64_t n_clicks, int64_t n_graphs, int d, int normalize, float eps, float* out,
-                       int64_t ld_out, void* stream);
+                       int64_t n_clicks, int64_t n_graphs, int d, int normalize, float eps, int reduce_sum,
+                       float* out, int64_t ld_out, void* stream);
+
+/* ---- other conv / pool variants of the reference on the same CSR / segment layout (d <= 256):
+ * csr_mean: out[i] = mean over the incoming edges of target i of x[col[e]] (0 without edges) -- the
+ *   aggregation of PyG SAGEConv (model/gnn.py:89-121).
+ * segment_reduce: out[g] = mean (mode 0) / sum (1) / max (2) of rows [ptr[g], ptr[g+1]) of x, each
+ *   row first scaled by w[r] when w != NULL -- GraphPooling (model/gnn.py:123-143) and the
+ *   last_click_mask sum of SRGNN_Pooling (model/gnn.py:172).
+ * attention_dot_pool: out[g] = mean_i(x_i <x_i, mean_g>) -- AttentionPooling (model/gnn.py:145-161). */
+int sss_csr_mean(const float* x, int64_t ld_x, const int32_t* rowptr, const int32_t* col, int64_t n_dst, int d,
+                 float* out, int64_t ld_out, void* stream);
+int sss_segment_reduce(const float* x, int64_t ld_x, const float* w, const int32_t* ptr, int64_t n_graphs, int d,
+                       int mode, float* out, int64_t ld_out, void* stream);
+int sss_attention_dot_pool(const float* x, int64_t ld_x, const int32_t* ptr, int64_t n_graphs, int d, float* out,
+                           int64_t ld_out, void* stream);
 
 /* ---- action table -> batched session graphs, on device: the structural part of
  * sequence_to_graph (util_amazon_filtered.py:98-230) + Batch.from_data_list

@@ -1,0 +1,40 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence kept under profiles/ (run on the GPU box through gpurun, from the
+# repo root):   bash scripts/collect_profiles.sh r02
+# Kernel-trace/stats passes and PMC passes are separate rocprofv3 runs (gpurun refuses a combination;
+# FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# The program sits directly after `--` (no env/bash hop).
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+BENCH="bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+stats() {   # name, args...
+    local name=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$name" -- python3 "$@" > "$OUT/$name.log" 2>&1
+    cat "$OUT/$name"/*/*kernel_stats.csv > "$OUT/${name}_kernel_stats.csv" 2>/dev/null
+    grep '^{"metric"' "$OUT/$name.log" > "$OUT/${name}_line.json" 2>/dev/null
+    echo "[$name] done"
+}
+pmc() {     # name, counters, args...
+    local name=$1; local ctr=$2; shift 2
+    rocprofv3 --pmc $ctr --output-format csv -d "$OUT/$name" -- python3 "$@" > "$OUT/$name.log" 2>&1
+    cat "$OUT/$name"/*/*counter_collection.csv > "$OUT/${name}_counters.csv" 2>/dev/null
+    echo "[$name] done"
+}
+stats bench_default $BENCH
+stats bench_c4_10m bench.py --steps 10 --warmup 2 --no-cpu-baseline --corpus-rows 10000000 --corpus-source random
+stats bench_c5_bf16 bench.py --steps 10 --warmup 2 --no-cpu-baseline --corpus-rows 10000000 --corpus-source random --dtype bf16 --d 256 --nq 4096
+stats bench_c3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload c3 --corpus-rows 1000000
+stats encoder scripts/bench_encoder.py 1024
+stats search_shapes scripts/quick_search_bench.py 1024,125000,128,10 1024,1000000,128,10 1024,125000,64,10 1024,125000,128,100
+PM="bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+pmc pmc_fetch FETCH_SIZE $PM
+pmc pmc_write WRITE_SIZE $PM
+pmc pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" $PM
+pmc pmc_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" $PM
+PM5="bench.py --steps 4 --warmup 1 --no-cpu-baseline --corpus-rows 10000000 --corpus-source random --dtype bf16 --d 256 --nq 4096"
+pmc pmc_fetch_c5 FETCH_SIZE $PM5
+pmc pmc_mfma_c5 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" $PM5
+ls -la "$OUT"

@@ -65,7 +65,10 @@ _SIGNATURES = {
     "sss_pool_expand_mean": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "sss_pool_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
-                                   c_int64, c_int64, c_int, c_int, c_float, c_void_p, c_int64, c_void_p]),
+                                   c_int64, c_int64, c_int, c_int, c_float, c_int, c_void_p, c_int64, c_void_p]),
+    "sss_csr_mean": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "sss_segment_reduce": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "sss_attention_dot_pool": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
 }
 
 
@@ -73,7 +76,7 @@ class LinearProblem(ctypes.Structure):
     """``sss_linear_problem`` of include/sss.h."""
     _fields_ = [("x", c_void_p), ("ldx", c_int64), ("ids", c_void_p), ("table", c_void_p), ("xcopy", c_void_p),
                 ("ld_xcopy", c_int64), ("w", c_void_p), ("ldw", c_int64), ("bias", c_void_p), ("y", c_void_p),
-                ("ldy", c_int64), ("n", c_int64), ("m", c_int32), ("reserved", c_int32)]
+                ("ldy", c_int64), ("n", c_int64), ("m", c_int32), ("act", c_int32)]
 
 
 class GraphOut(ctypes.Structure):

@@ -53,7 +53,7 @@ int segment_ptr(const long*, long, long, int*, hipStream_t);
 
 struct LinProb {
     const float* x; long ldx; const long* ids; const float* table; float* xcopy; long ld_xcopy;
-    const float* w; long ldw; const float* bias; float* y; long ldy; long n; int m; int tiles_m, tile_begin;
+    const float* w; long ldw; const float* bias; float* y; long ldy; long n; int m; int act; int tiles_m, tile_begin;
 };
 struct LinBatch { LinProb p[4]; int nprob; int K; };
 int linear_grouped(LinBatch&, hipStream_t);
@@ -68,7 +68,10 @@ int layer_update(const LayerArgs&, hipStream_t);
 int pool_expand_mean(const float*, const float*, long, const int*, const int*, const int*, const int*, long, long, int, int,
                      const float*, float*, long, float*, long, hipStream_t);
 int pool_attention(const float*, long, const float*, long, const float*, long, const float*, const int*, const int*, long, long,
-                   int, int, float, float*, long, hipStream_t);
+                   int, int, float, int, float*, long, hipStream_t);
+int csr_mean(const float*, long, const int*, const int*, long, int, float*, long, hipStream_t);
+int segment_reduce(const float*, long, const float*, const int*, long, int, int, float*, long, hipStream_t);
+int attention_dot_pool(const float*, long, const int*, long, int, float*, long, hipStream_t);
 int item_vote(const float*, const long*, long, int, const long*, const int*, long, long, int, long*, double*, int*, hipStream_t);
 size_t hamming_workspace_bytes(long nq, long n);
 int hamming_topk(const unsigned char*, long, const unsigned char*, long, int, int, long, int*, long*, int*, void*, size_t, hipStream_t);
@@ -173,7 +176,7 @@ int sss_linear_grouped(const sss_linear_problem* problems, int n_problems, int k
         sss::LinProb& p = b.p[i];
         p.x = s.x; p.ldx = s.ldx; p.ids = reinterpret_cast<const long*>(s.ids); p.table = s.table; p.xcopy = s.xcopy;
         p.ld_xcopy = s.ld_xcopy; p.w = s.w; p.ldw = s.ldw; p.bias = s.bias; p.y = s.y; p.ldy = s.ldy; p.n = s.n; p.m = s.m;
-        p.tiles_m = 0; p.tile_begin = 0;
+        p.act = s.act; p.tiles_m = 0; p.tile_begin = 0;
     }
     return sss::linear_grouped(b, ST(stream));
 }
@@ -196,9 +199,21 @@ int sss_pool_expand_mean(const float* lin_p, const float* lin_q, int64_t ld_lin,
 }
 int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64_t ld_a, const float* b, int64_t ld_b,
                        const float* watt, const int32_t* pptr, const int32_t* qptr, int64_t n_clicks, int64_t n_graphs,
-                       int d, int normalize, float eps, float* out, int64_t ld_out, void* stream) {
-    return sss::pool_attention(node, ld_node, a, ld_a, b, ld_b, watt, pptr, qptr, n_clicks, n_graphs, d, normalize, eps, out,
-                               ld_out, ST(stream));
+                       int d, int normalize, float eps, int reduce_sum, float* out, int64_t ld_out, void* stream) {
+    return sss::pool_attention(node, ld_node, a, ld_a, b, ld_b, watt, pptr, qptr, n_clicks, n_graphs, d, normalize, eps,
+                               reduce_sum, out, ld_out, ST(stream));
+}
+int sss_csr_mean(const float* x, int64_t ld_x, const int32_t* rowptr, const int32_t* col, int64_t n_dst, int d, float* out,
+                 int64_t ld_out, void* stream) {
+    return sss::csr_mean(x, ld_x, rowptr, col, n_dst, d, out, ld_out, ST(stream));
+}
+int sss_segment_reduce(const float* x, int64_t ld_x, const float* w, const int32_t* ptr, int64_t n_graphs, int d, int mode,
+                       float* out, int64_t ld_out, void* stream) {
+    return sss::segment_reduce(x, ld_x, w, ptr, n_graphs, d, mode, out, ld_out, ST(stream));
+}
+int sss_attention_dot_pool(const float* x, int64_t ld_x, const int32_t* ptr, int64_t n_graphs, int d, float* out,
+                           int64_t ld_out, void* stream) {
+    return sss::attention_dot_pool(x, ld_x, ptr, n_graphs, d, out, ld_out, ST(stream));
 }
 int sss_pack_sign_bits(const float* x, int64_t n, int c, int64_t ldx, uint8_t* out, int nbytes, void* stream) {
     return sss::pack_sign_bits(x, n, c, ldx, out, nbytes, ST(stream));

@@ -61,6 +61,69 @@ __global__ __launch_bounds__(64) void k_exact_scores(const void* __restrict__ Qv
     }
 }
 
+// Fast scorer for the fused kernel's shapes (d = 64 / 128 / 256 elements per row): a lane keeps
+// ONE corpus row in registers and walks all selected queries (staged through LDS in chunks, read
+// back as broadcasts), so the corpus is read once however many queries need the backstop
+// (k_exact_scores above re-reads it per query).  Same canonical score: sequential float64 sum.
+template <int D, int DT>
+__global__ __launch_bounds__(256) void k_exact_scores_rows(const void* __restrict__ Qv, const int* __restrict__ qsel, int nsel,
+                                                           const void* __restrict__ Cv, long n, float* __restrict__ scores) {
+    constexpr int QC = 8192 / D;                       // queries per LDS chunk (32 KiB of float32)
+    __shared__ __attribute__((aligned(16))) float qs[QC * D];
+    constexpr int EB = DT == DT_F32 ? 4 : 2;
+    const char* C = reinterpret_cast<const char*>(Cv);
+    const char* Q = reinterpret_cast<const char*>(Qv);
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    const long rl = row < n ? row : n - 1;
+    float r[D];
+    if (DT == DT_F32) {
+#pragma unroll
+        for (int v = 0; v < D / 4; ++v) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(C + ((size_t)rl * D + v * 4) * EB);
+            r[4 * v] = c4.x; r[4 * v + 1] = c4.y; r[4 * v + 2] = c4.z; r[4 * v + 3] = c4.w;
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < D / 8; ++v) {
+            const uint4 c4 = *reinterpret_cast<const uint4*>(C + ((size_t)rl * D + v * 8) * EB);
+            const unsigned u[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r[8 * v + 2 * e] = __builtin_bit_cast(float, u[e] << 16);
+                r[8 * v + 2 * e + 1] = __builtin_bit_cast(float, u[e] & 0xFFFF0000u);
+            }
+        }
+    }
+    for (int f0 = 0; f0 < nsel; f0 += QC) {
+        const int nf = nsel - f0 < QC ? nsel - f0 : QC;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nf * D; i += 256) {
+            const int f = i / D, kx = i % D;
+            const char* qrow = Q + (size_t)qsel[f0 + f] * D * EB;
+            qs[i] = DT == DT_F32 ? reinterpret_cast<const float*>(qrow)[kx]
+                                 : __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(qrow)[kx] << 16);
+        }
+        __syncthreads();
+        for (int f = 0; f < nf; f += 2) {                  // two queries at a time: two independent float64 chains
+            const int f1 = f + 1 < nf ? f + 1 : f;
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int v = 0; v < D / 4; ++v) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(qs + f * D + v * 4);     // same address in every lane
+                const f32x4 p4 = *reinterpret_cast<const f32x4*>(qs + f1 * D + v * 4);
+                acc0 += (double)q4.x * (double)r[4 * v];     acc1 += (double)p4.x * (double)r[4 * v];
+                acc0 += (double)q4.y * (double)r[4 * v + 1]; acc1 += (double)p4.y * (double)r[4 * v + 1];
+                acc0 += (double)q4.z * (double)r[4 * v + 2]; acc1 += (double)p4.z * (double)r[4 * v + 2];
+                acc0 += (double)q4.w * (double)r[4 * v + 3]; acc1 += (double)p4.w * (double)r[4 * v + 3];
+            }
+            if (row < n) {
+                scores[(size_t)(f0 + f) * n + row] = (float)acc0;
+                if (f + 1 < nf) scores[(size_t)(f0 + f + 1) * n + row] = (float)acc1;
+            }
+        }
+    }
+}
+
 // One block per selected query: exact top-k of its n canonical scores in O(n):
 //   1. radix select (4 passes of 8 bits over the order-preserving uint of the score, LDS
 //      histograms) -> T = the k-th best score and how many rows tied at T are still needed;
@@ -92,9 +155,37 @@ __global__ __launch_bounds__(RS_THREADS) void k_topk_radix(const float* __restri
             const int shift = 24 - 8 * pass;
             for (int i = tid; i < 256; i += RS_THREADS) hist[i] = 0;
             __syncthreads();
-            for (long i = tid; i < n; i += RS_THREADS) {
-                const unsigned key = key_of(i);
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            // four independent loads in flight per thread (the passes are latency-bound otherwise);
+            // whole waves stay in the loop so the ballots below are convergent
+            const long n_up = (n + 4 * RS_THREADS - 1) / (4 * RS_THREADS) * (4 * RS_THREADS);
+            for (long i0 = tid; i0 < n_up; i0 += 4 * RS_THREADS) {
+                unsigned keyv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long i = i0 + (long)u * RS_THREADS;
+                    keyv[u] = i < n ? key_of(i) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long i = i0 + (long)u * RS_THREADS;
+                    const unsigned key = keyv[u];
+                    const bool act = i < n && (key & mask) == prefix;
+                    const unsigned b = (key >> shift) & 255u;
+                    if (pass == 0) {
+                        // sign and exponent bits are shared by most scores: one LDS atomic per
+                        // DISTINCT bucket of the wave instead of 64 serialised ones on the same address
+                        unsigned long long todo = __builtin_amdgcn_ballot_w64(act);
+                        while (todo) {
+                            const int leader = __builtin_ctzll(todo);
+                            const unsigned lb = (unsigned)__builtin_amdgcn_readlane((int)b, leader);
+                            const unsigned long long m = __builtin_amdgcn_ballot_w64(act && b == lb);
+                            if (lane == leader) atomicAdd(&hist[lb], (unsigned)__builtin_popcountll(m));
+                            todo &= ~m;
+                        }
+                    } else if (act) {
+                        atomicAdd(&hist[b], 1u);
+                    }
+                }
             }
             __syncthreads();
             if (tid == 0) {
@@ -118,11 +209,20 @@ __global__ __launch_bounds__(RS_THREADS) void k_topk_radix(const float* __restri
     __syncthreads();
     // ---- rows strictly better than T (fewer than kk of them), in any order
     if (kk < n) {
-        for (long i = tid; i < n; i += RS_THREADS) {
-            const unsigned key = key_of(i);
-            if (key > T) {
-                const unsigned p = atomicAdd(&s_count, 1u);
-                keys[p] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)i);
+        for (long i0 = tid; i0 < n; i0 += 4 * RS_THREADS) {
+            unsigned keyv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long i = i0 + (long)u * RS_THREADS;
+                keyv[u] = i < n ? key_of(i) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long i = i0 + (long)u * RS_THREADS;
+                if (i < n && keyv[u] > T) {
+                    const unsigned p = atomicAdd(&s_count, 1u);
+                    keys[p] = ((unsigned long long)keyv[u] << 32) | (unsigned)(~(unsigned)i);
+                }
             }
         }
     }
@@ -195,10 +295,18 @@ int ip_topk_exhaustive(const void* q, const int* qsel, long nsel, const void* c,
     float* scores = reinterpret_cast<float*>(ws);
     long gx = (n + EX_ROWS - 1) / EX_ROWS;
     if (gx > 8192) gx = 8192;
-    if (dtype == DT_F32)
+    const unsigned rb = (unsigned)((n + 255) / 256);
+#define SSS_ROWS(D_, DT_) hipLaunchKernelGGL((k_exact_scores_rows<D_, DT_>), dim3(rb), dim3(256), 0, st, q, qsel, (int)nsel, c, n, scores)
+    if (metric == 0 && dtype == DT_F32 && d == 64) SSS_ROWS(64, DT_F32);
+    else if (metric == 0 && dtype == DT_F32 && d == 128) SSS_ROWS(128, DT_F32);
+    else if (metric == 0 && dtype == DT_F32 && d == 256) SSS_ROWS(256, DT_F32);
+    else if (metric == 0 && dtype == DT_BF16 && d == 128) SSS_ROWS(128, DT_BF16);
+    else if (metric == 0 && dtype == DT_BF16 && d == 256) SSS_ROWS(256, DT_BF16);
+    else if (dtype == DT_F32)
         hipLaunchKernelGGL(k_exact_scores<DT_F32>, dim3((unsigned)gx, (unsigned)nsel), dim3(64), 0, st, q, qsel, c, n, d, metric, scores);
     else
         hipLaunchKernelGGL(k_exact_scores<DT_BF16>, dim3((unsigned)gx, (unsigned)nsel), dim3(64), 0, st, q, qsel, c, n, d, metric, scores);
+#undef SSS_ROWS
     int rc = check_launch("k_exact_scores");
     if (rc) return rc;
     hipLaunchKernelGGL(k_topk_radix, dim3((unsigned)nsel), dim3(RS_THREADS), 0, st, scores, qsel, n, k, id_offset, metric, D_out, I_out);

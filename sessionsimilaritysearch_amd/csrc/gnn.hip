@@ -459,6 +459,7 @@ struct LinProb {
     const float* w; long ldw; const float* bias;
     float* y; long ldy;
     long n; int m;
+    int act;                           // epilogue: 0 none, 1 relu, 2 tanh
     int tiles_m, tile_begin;           // filled by the launcher
 };
 struct LinBatch { LinProb p[4]; int nprob; int K; };
@@ -479,10 +480,11 @@ __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
     const float* X = B.p[0].x; long ldx = B.p[0].ldx; const long* ids = B.p[0].ids; const float* table = B.p[0].table;
     float* xcopy = B.p[0].xcopy; long ldc = B.p[0].ld_xcopy; const float* W = B.p[0].w; long ldw = B.p[0].ldw;
     const float* bias = B.p[0].bias; float* Y = B.p[0].y; long ldy = B.p[0].ldy; long N = B.p[0].n; int M = B.p[0].m;
-    int tiles_m = B.p[0].tiles_m, tile_begin = B.p[0].tile_begin;
+    int tiles_m = B.p[0].tiles_m, tile_begin = B.p[0].tile_begin, act = B.p[0].act;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
         if (pi == i) {
+            act = B.p[i].act;
             X = B.p[i].x; ldx = B.p[i].ldx; ids = B.p[i].ids; table = B.p[i].table; xcopy = B.p[i].xcopy; ldc = B.p[i].ld_xcopy;
             W = B.p[i].w; ldw = B.p[i].ldw; bias = B.p[i].bias; Y = B.p[i].y; ldy = B.p[i].ldy; N = B.p[i].n; M = B.p[i].m;
             tiles_m = B.p[i].tiles_m; tile_begin = B.p[i].tile_begin;
@@ -547,7 +549,10 @@ __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const long row = row0 + wr * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-            if (row < N) Y[row * ldy + col] = acc[j] + bv;
+            float v = acc[j] + bv;
+            if (act == 1) v = fmaxf(v, 0.f);
+            else if (act == 2) v = tanhf(v);
+            if (row < N) Y[row * ldy + col] = v;
         }
     }
 }
@@ -731,8 +736,8 @@ __global__ __launch_bounds__(256) void k_pool_attention(const float* __restrict_
                                                         const float* __restrict__ Bc, long ld_b,
                                                         const float* __restrict__ watt, const int* __restrict__ pptr,
                                                         const int* __restrict__ qptr, long n_clicks, long n_graphs,
-                                                        int D, int normalize, float eps, float* __restrict__ out,
-                                                        long ld_out) {
+                                                        int D, int normalize, float eps, int reduce_sum,
+                                                        float* __restrict__ out, long ld_out) {
     const int sub = threadIdx.x % LPR;
     const long g = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     const int c4 = sub * 4;
@@ -768,7 +773,7 @@ __global__ __launch_bounds__(256) void k_pool_attention(const float* __restrict_
         load_row(t, a0, v0); load_row(t + 1, a1, v1); load_row(t + 2, a2, v2); load_row(t + 3, a3, v3);
         finish_row(a0, v0); finish_row(a1, v1); finish_row(a2, v2); finish_row(a3, v3);
     }
-    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    const float inv = reduce_sum ? 1.f : 1.f / (float)(cnt > 0 ? cnt : 1);       // sum: SRGNN_Pooling's global_add_pool
     acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
     if (normalize) {
         float ss = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
@@ -837,8 +842,8 @@ int pool_expand_mean(const float* lin_p, const float* lin_q, long ld_lin, const 
 }
 
 int pool_attention(const float* node, long ld_node, const float* Aa, long ld_a, const float* Bc, long ld_b, const float* watt,
-                   const int* pptr, const int* qptr, long n_clicks, long n_graphs, int D, int normalize, float eps, float* out,
-                   long ld_out, hipStream_t st) {
+                   const int* pptr, const int* qptr, long n_clicks, long n_graphs, int D, int normalize, float eps, int reduce_sum,
+                   float* out, long ld_out, hipStream_t st) {
     if (n_graphs < 0 || D <= 0 || D % 4 || D > 256 || ld_node % 4 || ld_a % 4 || ld_b % 4 || ld_out % 4 || ld_out < D) {
         set_error("pool_attention: need D %% 4 == 0, D <= 256, 16-byte aligned row strides");
         return SSS_EINVAL;
@@ -847,8 +852,8 @@ int pool_attention(const float* node, long ld_node, const float* Aa, long ld_a, 
     const int lpr = lanes_for(D);
     const long per = 256 / lpr;
     SSS_LPR_SWITCH(lpr, hipLaunchKernelGGL(k_pool_attention<L>, dim3((unsigned)((n_graphs + per - 1) / per)), dim3(256), 0, st, node,
-                                           ld_node, Aa, ld_a, Bc, ld_b, watt, pptr, qptr, n_clicks, n_graphs, D, normalize, eps, out,
-                                           ld_out));
+                                           ld_node, Aa, ld_a, Bc, ld_b, watt, pptr, qptr, n_clicks, n_graphs, D, normalize, eps,
+                                           reduce_sum, out, ld_out));
     return check_launch("k_pool_attention");
 }
 

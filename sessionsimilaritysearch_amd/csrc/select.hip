@@ -10,7 +10,9 @@
 //                  below the selection edge (it lost to a full list's tail <= edge, or to the
 //                  admission threshold < edge, or it is a candidate ranked below the edge), and
 //                  edge + 2B < k-th re-scored score, B bounding the scan's rounding error;
-//             = 1  not proven -> the caller re-runs the query through the exhaustive path.
+//            != 0  not proven (bit 0: a full list's tail outranks the edge, bit 1: the admission
+//                  threshold does, bit 2: near-tie window) -> the caller re-runs the query through
+//                  the exhaustive path.
 //   k_select_fast  : one wave per query, K2 <= 32, candidates <= FS_CAP (the common case: the
 //                    shared threshold leaves a few hundred candidates per query)
 //   k_select_sort  : one workgroup per query, bitonic sort in LDS, any K2 <= SEL_MAX_K2
@@ -126,12 +128,12 @@ __device__ __forceinline__ int decide_status(unsigned long long edge, unsigned l
                                              int J, int nvalid, int k, double kth, double B) {
     int st = 0;
     const bool edge_real = edge != 0 && key_id(edge) >= 0;
-    if (maxlast > edge) st = 1;                                   // a full list may hide a contender
+    if (maxlast > edge) st |= 1;                                  // a full list may hide a contender
     if (J > 0 && tau_o > ORD_NEG_INF) {                           // rows were rejected at or below ord2f(tau_o - 1)
-        if (!(edge_real && f2ord(key_score(edge)) >= tau_o)) st = 1;
+        if (!(edge_real && f2ord(key_score(edge)) >= tau_o)) st |= 2;
     }
     if (edge_real && nvalid >= k) {
-        if ((double)key_score(edge) + 2.0 * B >= kth) st = 1;     // float32 near-tie window reaches the edge
+        if ((double)key_score(edge) + 2.0 * B >= kth) st |= 4;    // float32 near-tie window reaches the edge
     }
     return st;
 }

@@ -409,7 +409,7 @@ class SessionEncoder:
                       ids=0 if ids is None else ids.data_ptr(), table=0 if table is None else table.data_ptr(),
                       xcopy=0 if xcopy is None else xcopy.data_ptr(), ld_xcopy=0 if xcopy is None else xcopy.stride(0),
                       w=w.data_ptr(), ldw=w.stride(0), bias=0 if bias is None else bias.data_ptr(),
-                      y=y.data_ptr(), ldy=y.stride(0), n=n, m=m, reserved=0)
+                      y=y.data_ptr(), ldy=y.stride(0), n=n, m=m, act=0)
 
         steps, keep = [], []
         for l, lw in enumerate(self.layers):
@@ -482,7 +482,7 @@ class SessionEncoder:
         out = torch.empty((pb.B, D), dtype=torch.float32, device=dev)
         rc = L.sss_pool_attention(ws["node"].data_ptr(), D, ws["A"].data_ptr(), D, ws["Bc"].data_ptr(), D, pw["watt"].data_ptr(),
                                   pb.pptr.data_ptr(), pb.qptr.data_ptr(), pb.n_clicks, pb.B, D, 1 if l2_normalize else 0,
-                                  1e-6, out.data_ptr(), D, st)
+                                  1e-6, 0, out.data_ptr(), D, st)
         _lib.check(rc, "sss_pool_attention")
         return out, NQ, NP
 

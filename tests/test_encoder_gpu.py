@@ -214,7 +214,7 @@ def test_pooling_kernels_match_oracle_on_their_own(cuda):
     P_ = _lib.LinearProblem
     mk = lambda x, wt, bias, y, n, m: P_(x=x.data_ptr(), ldx=x.stride(0), ids=0, table=0, xcopy=0, ld_xcopy=0, w=wt.data_ptr(),
                                           ldw=wt.stride(0), bias=0 if bias is None else bias.data_ptr(), y=y.data_ptr(),
-                                          ldy=y.stride(0), n=n, m=m, reserved=0)
+                                          ldy=y.stride(0), n=n, m=m, act=0)
     arr = (P_ * 2)(mk(NP, pw["wp"], pw["bp"], lin_p, pb.Np, Dl), mk(NQ, pw["wq"], pw["bq"], lin_q, pb.Nq, Dl))
     _lib.check(L.sss_linear_grouped(arr, 2, W, _st(cuda)), "lin")
     n_exp = pb.n_clicks + pb.Nq
@@ -227,7 +227,7 @@ def test_pooling_kernels_match_oracle_on_their_own(cuda):
     _lib.check(L.sss_linear_grouped(arr2, 2, D, _st(cuda)), "lin2")
     out = torch.empty((pb.B, D), device=cuda)
     _lib.check(L.sss_pool_attention(node.data_ptr(), D, A.data_ptr(), D, Bc.data_ptr(), D, pw["watt"].data_ptr(),
-                                    pb.pptr.data_ptr(), pb.qptr.data_ptr(), pb.n_clicks, pb.B, D, 0, 1e-6, out.data_ptr(), D,
+                                    pb.pptr.data_ptr(), pb.qptr.data_ptr(), pb.n_clicks, pb.B, D, 0, 1e-6, 0, out.data_ptr(), D,
                                     _st(cuda)), "att")
     assert (out.cpu() - ref).abs().max() < TOL * max(1.0, float(ref.abs().max()))
 

@@ -1,0 +1,93 @@
+"""GPU parity of the reference's other conv / pool variants against
+oracle/variants_ref.py.  Floating point: tolerance 1e-5 (BASELINE north_star), on O(1) values."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import variants_ref as vr
+from sessionsimilaritysearch_amd import sessions as S
+from sessionsimilaritysearch_amd.encoder import EncoderConfig, SessionEncoder, init_weights
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _rand(g, *shape, scale=1.0):
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _batch(cuda, n=80, seed=70):
+    cfg = EncoderConfig(d_in=64, h=64, n_layers=1, d_out=64, n_items=500, n_query=65, self_loop_rule="none")
+    enc = SessionEncoder(cfg, init_weights(cfg, seed), cuda)
+    acts = S.synthetic_actions(n, seed, 500, 65)
+    return S.build_batch(acts).to_torch("cpu"), enc.prepare_actions(acts)
+
+
+def test_hetero_sage_matches_oracle(cuda):
+    from sessionsimilaritysearch_amd.variants import HeteroSAGE
+    b, pb = _batch(cuda)
+    g = torch.Generator().manual_seed(71)
+    d, h = 64, 96
+    w = {}
+    for l in range(3):
+        din = d if l == 0 else h
+        for e in ("qp", "pq", "pp"):
+            w[f"sage.{l}.{e}.lin_l.w"] = _rand(g, h, din, scale=0.2)
+            w[f"sage.{l}.{e}.lin_l.b"] = _rand(g, h, scale=0.2)
+            w[f"sage.{l}.{e}.lin_r.w"] = _rand(g, h, din, scale=0.2)
+    xq, xp = torch.randn((pb.Nq, d), generator=g), torch.randn((pb.Np, d), generator=g)
+    ref = vr.hetero_sage(xq, xp, b.edge_index_dict, w)
+    got = HeteroSAGE(w, 3, cuda).forward(xq.to(cuda), xp.to(cuda), pb.csr_qp[:2], pb.csr_pq[:2], pb.csr_pp[:2])
+    for t in ("query", "product"):
+        assert (got[t].cpu() - ref[t]).abs().max() < TOL * max(1.0, float(ref[t].abs().max()))
+
+
+def test_graph_attention_srgnn_pooling_match_oracle(cuda):
+    from sessionsimilaritysearch_amd.variants import AttentionPooling, GraphPooling, SRGNNPooling
+    b, pb = _batch(cuda, 120, 72)
+    g = torch.Generator().manual_seed(72)
+    d, out = 64, 96
+    x = torch.randn((pb.Np, d), generator=g)
+    batch, B = b["product"].batch, b.num_graphs
+    ptr = pb.p_ptr
+    lin = {"lin.w": _rand(g, out, d, scale=0.2), "lin.b": _rand(g, out, scale=0.2)}
+    xd = x.to(cuda)
+    for key in ("mean", "add", "max"):
+        ref = vr.graph_pooling(x, batch, B, key, lin)
+        got = GraphPooling(key, lin, cuda).forward(xd, ptr).cpu()
+        assert (got - ref).abs().max() < TOL * max(1.0, float(ref.abs().max())), key
+    with pytest.raises(Exception):
+        GraphPooling("sort", lin, cuda)
+    ref = vr.attention_pooling(x, batch, B, lin)
+    got = AttentionPooling(lin, cuda).forward(xd, ptr).cpu()
+    assert (got - ref).abs().max() < 2 * TOL * max(1.0, float(ref.abs().max()))
+    w = {"lin1.w": _rand(g, d, d, scale=0.2), "lin1.b": _rand(g, d, scale=0.2), "lin2.w": _rand(g, d, d, scale=0.2),
+         "lin2.b": _rand(g, d, scale=0.2), "lin3.w": _rand(g, 1, d, scale=0.3), "lin4.w": _rand(g, out, 2 * d, scale=0.2),
+         "lin4.b": _rand(g, out, scale=0.2)}
+    mask = torch.zeros(pb.Np)
+    mask[(pb.p_ptr[1:].cpu().long() - 1)] = 1.0                       # the last product node of every graph
+    ref = vr.srgnn_pooling(x, batch, B, mask, w)
+    got = SRGNNPooling(w, cuda).forward(xd, ptr, mask).cpu()
+    assert (got - ref).abs().max() < TOL * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("jump,last_act", [(False, True), (True, False)])
+def test_mlp_head_matches_oracle(cuda, jump, last_act):
+    from sessionsimilaritysearch_amd.variants import MLPHead
+    g = torch.Generator().manual_seed(73)
+    n_in, n_hid, n_out, nh = 64, 96, 32, 2
+    w = {}
+    dims = [n_in] + [n_hid] * (nh + 1)
+    for i in range(nh + 1):
+        w[f"layers.{i}.w"] = _rand(g, dims[i + 1], dims[i], scale=0.3)
+        w[f"layers.{i}.b"] = _rand(g, dims[i + 1], scale=0.3)
+        w[f"bn.{i}.mean"] = _rand(g, n_hid, scale=0.2)
+        w[f"bn.{i}.var"] = torch.rand(n_hid, generator=g) + 0.5
+        w[f"bn.{i}.gamma"] = torch.rand(n_hid, generator=g) + 0.5
+        w[f"bn.{i}.beta"] = _rand(g, n_hid, scale=0.2)
+    w[f"layers.{nh + 1}.w"] = _rand(g, n_out, n_hid + (n_in if jump else 0), scale=0.3)
+    w[f"layers.{nh + 1}.b"] = _rand(g, n_out, scale=0.3)
+    x = torch.randn((333, n_in), generator=g)
+    ref = vr.mlp(x, w, nh, last_act, jump)
+    got = MLPHead(w, nh, cuda, last_act, jump).forward(x.to(cuda)).cpu()
+    assert (got - ref).abs().max() < TOL * max(1.0, float(ref.abs().max()))
