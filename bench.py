@@ -305,14 +305,15 @@ def main():
                          f"float32 SGEMM/top-k (faiss-shaped) over {sample} of {n_total} corpus rows "
                          f"({t_search:.3f}s, scaled linearly to the full corpus)"}
 
-    traffic = None
+    traffic = traffic_detail = None
     tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if os.path.exists(tpath):       # per-launch HBM bytes measured by the committed rocprofv3 --pmc passes
         with open(tpath) as f:
             tj = json.load(f)
         key = f"{args.dtype}:{d}:{nq}:{hi - lo}"
         if key in tj:
-            traffic = tj[key]
+            traffic_detail = tj[key]
+            traffic = traffic_detail["total_bytes"]
     peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -338,7 +339,8 @@ def main():
                        "items_bit_exact": items_exact, "queries_checked": nrq}} if c3 else {}),
             "roofline": {"bound": "mfma", "kernel": f"k_scan<{d * (4 if args.dtype == 'f32' else 2)},*,{args.dtype}>",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "B per launch (HBM, rocprofv3 PMC)",
+                         "traffic_detail": traffic_detail,
                          "kernel_ms": round(kern_ms, 4), "launches": launches.value,
                          "flop_per_launch": flop_per_launch},
             "cpu_baseline": cpu,
