@@ -10,7 +10,7 @@ constexpr int DT_BF16 = 1;
 
 constexpr int KP = 16;          // per-lane candidate list length (register resident)
 constexpr int WG_QUERIES = 256; // queries per scan workgroup (8 waves x 32)
-constexpr int MAX_SLOTS = 64;   // admission-threshold slots per query (J <= MAX_SLOTS)
+constexpr int MAX_SLOTS = 128;  // admission-threshold slots per query (J <= MAX_SLOTS)
 constexpr unsigned ORD_NEG_INF = 0x007FFFFFu;   // f2ord(-inf); slot value 0 = "never written"
 
 static inline int elem_bytes(int dtype) { return dtype == DT_BF16 ? 2 : 4; }

@@ -429,11 +429,15 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     p.total_tiles = (int)((n + tr - 1) / tr);
     p.tiles_per_split = (p.total_tiles + S - 1) / S;
     p.cap = p.L * KP;
-    // threshold slots: J classes x cert entries certify J * cert >= K2 rows (scan.hip header)
-    p.J = p.K2 <= 128 ? 16 : MAX_SLOTS;
+    // threshold slots: J classes x cert entries certify J * cert >= K2 rows (scan.hip header).
+    // K2 <= 16: 16 classes of class maxima (cert 1, with the bootstrap; refreshed through LDS-DMA
+    // every iteration).  Larger K2: 16 (64 beyond K2 = 128) classes certify `cert` rows each with
+    // their lists' cert-th best -- measured faster than one class per row, whose 7+ slot loads per
+    // refresh have to be synchronous.
+    const int active_splits = (p.total_tiles + p.tiles_per_split - 1) / p.tiles_per_split;
+    p.J = p.K2 <= 128 ? 16 : 64;
     p.cert = 1;
     while (p.J * p.cert < p.K2 && p.cert < KP) p.cert *= 2;
-    const int active_splits = (p.total_tiles + p.tiles_per_split - 1) / p.tiles_per_split;
     if (p.J * p.cert < p.K2 || 2 * active_splits < p.J) p.J = 0;      // tiny corpus: no threshold
     p.boot = (p.J > 0 && p.cert == 1) ? 1 : 0;
     p.off_cand = 0;

@@ -20,9 +20,9 @@
 
 namespace sss {
 
-constexpr int FS_CAP = 1024;       // candidates a wave stages in LDS (more -> unproven)
-constexpr int FS_ROWS = 16;        // rows re-scored per pass
-constexpr int FS_K2 = 32;
+constexpr int FS_CAP = 2048;       // candidates a wave stages in LDS (more -> unproven)
+constexpr int FS_K2 = 32;          // largest K2 of the wave-per-query kernel (k <= 20); beyond it K2 rounds of
+                                   // wave-wide arg-max lose to the bitonic sort of k_select_sort (measured at K2 = 112)
 constexpr int SEL_MAX_K2 = 512;
 constexpr int SORT_THREADS = 256;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -139,15 +139,14 @@ __device__ __forceinline__ int decide_status(unsigned long long edge, unsigned l
 }
 
 // ------------------------------------------------------------------------------------------
-// One wave per query.  LDS per wave: keys[FS_CAP] | sel[FS_K2] | resc[FS_K2] | qrow[RBmax] | rows
+// One wave per query.  LDS per wave: keys[FS_CAP] | sel[FS_K2] | resc[FS_K2] | counters | qrow[rb]
 __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= A.nq) return;                                        // whole wave; no block-level sync below
     const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
-    const int ldrow = rb + 16;
-    const size_t per_wave = (size_t)FS_CAP * 8 + FS_K2 * 16 + 16 + rb + (size_t)FS_ROWS * ldrow;
+    const size_t per_wave = (size_t)FS_CAP * 8 + FS_K2 * 16 + 16 + rb;
     char* base = smem + wv * ((per_wave + 15) & ~(size_t)15);
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(base);
     unsigned long long* sel = keys + FS_CAP;
@@ -155,7 +154,6 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     int* s_nvalid = reinterpret_cast<int*>(resc + FS_K2);
     double* s_kth = reinterpret_cast<double*>(s_nvalid + 2);
     char* qrow = reinterpret_cast<char*>(s_kth + 1);
-    char* rows = qrow + rb;
 
     const int K2 = A.K2, k = A.k;
     float* Dq = A.D_out + (size_t)q * k;
@@ -190,36 +188,26 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
             }
         }
     }
-    // ---- float64 re-score, FS_ROWS candidates per pass: rows staged with coalesced 16-byte
-    // loads, then one lane per candidate walks k sequentially (the canonical order)
-    const int nv = rb / 16;
-    double qn2 = 0.0;
     wave_sync();
-    for (int c0 = 0; c0 < K2; c0 += FS_ROWS) {
-        for (int i = lane; i < FS_ROWS * nv; i += 64) {
-            const int c = c0 + i / nv, v = i % nv;
-            const unsigned long long key = c < K2 ? sel[c] : 0;
-            const int id = key_id(key);
-            if (key != 0 && id >= 0)
-                *reinterpret_cast<f32x4*>(rows + (size_t)(i / nv) * ldrow + v * 16) =
-                    *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.C) + (size_t)id * rb + v * 16);
+    // ---- float64 re-score: one lane per candidate walks its corpus row (16-byte loads straight from
+    // L2 / HBM, several in flight) sequentially in k -- the canonical order
+    const int nv = rb / 16;
+    for (int c = lane; c < K2; c += 64) {
+        const unsigned long long key = sel[c];
+        double acc = 0.0;
+        if (key != 0 && key_id(key) >= 0) {
+            const char* row = reinterpret_cast<const char*>(A.C) + (size_t)key_id(key) * rb;
+#pragma unroll 8
+            for (int v = 0; v < nv; ++v)
+                acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
         }
-        wave_sync();
-        if (lane < FS_ROWS && c0 + lane < K2) {
-            const unsigned long long key = sel[c0 + lane];
-            double acc = 0.0;
-            if (key != 0 && key_id(key) >= 0) {
-                const char* row = rows + (size_t)lane * ldrow;
-                for (int v = 0; v < nv; ++v)
-                    acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
-            }
-            resc[c0 + lane] = acc;
-        }
-        wave_sync();
+        resc[c] = acc;
     }
+    double qn2 = 0.0;
     for (int kk = lane; kk < A.d; kk += 64) { const double v = elem_to_f32(qrow, kk, A.dtype); qn2 += v * v; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) qn2 += __shfl_xor(qn2, o);     // only feeds the error BOUND: order-free
+    wave_sync();
     rank_and_write<64>(sel, resc, K2, k, A.id_offset, Dq, Iq, lane, s_nvalid, s_kth);
     wave_sync();
     const int nvalid = *s_nvalid;
@@ -341,7 +329,7 @@ int launch_select(const SelectArgs& a, hipStream_t st) {
     const int rb = a.d * elem_bytes(a.dtype);
     const int dev = current_device();
     if (a.K2 <= FS_K2) {
-        const size_t per_wave = (((size_t)FS_CAP * 8 + FS_K2 * 16 + 16 + rb + (size_t)FS_ROWS * (rb + 16)) + 15) & ~(size_t)15;
+        const size_t per_wave = (((size_t)FS_CAP * 8 + FS_K2 * 16 + 16 + rb) + 15) & ~(size_t)15;
         const size_t lds = 4 * per_wave;
         static bool done[MAX_DEVICES] = {};
         if (!done[dev]) {
