@@ -66,13 +66,16 @@ __device__ __forceinline__ unsigned min8_sc1(const unsigned* p) {
     return min(m0, m1);
 }
 
-template <int RB, int TR, int DT>
-__global__ __launch_bounds__(512, 2) void k_scan(const ScanArgs A) {
+// NW = waves per workgroup: 8 (two per SIMD, 256 VGPRs each) or, for 1024-byte rows whose resident
+// queries alone take 128 VGPRs, 4 (one per SIMD, 512 VGPRs: no spills; NW * 32 queries per workgroup).
+template <int RB, int TR, int DT, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     constexpr int H = TR / 64;                        // 64-row sub-steps per tile
     constexpr int CH = RB / 16;                       // 16-byte chunks per row
     constexpr int NU = RB / 32;                       // k-groups per row (one b128 fragment each)
     constexpr int TILE_BYTES = TR * RB;
-    constexpr int LOADS_PER_WAVE = TR * CH / 64 / 8;  // LDS-DMA wave-instructions per wave per tile
+    constexpr int LOADS_PER_WAVE = TR * CH / 64 / NW; // LDS-DMA wave-instructions per wave per tile
+    constexpr int WGQ = NW * 32;                      // queries per workgroup
     constexpr bool PRECOMP = RB <= 512;               // keep the DMA lane offsets in VGPRs (register budget)
     constexpr int TAU_LDS = 2 * TILE_BYTES;           // [8 waves][32 queries][16 slots] u32 behind the two tile buffers
     static_assert(CH <= 64, "row longer than one LDS-DMA instruction");
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void k_scan(const ScanArgs A) {
 
     // ---- resident queries: lane (r, h) holds 16-byte chunk 2u + h of its query row in qc[u]
     const int q_local = wave * 32 + r;
-    const int q_glob = g * WG_QUERIES + q_local;
+    const int q_glob = g * WGQ + q_local;
     const int q_ld = q_glob < nq ? q_glob : nq - 1;
     f32x4 qc[NU];
     {
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void k_scan(const ScanArgs A) {
     auto tau_fetch = [&]() {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            int qi = g * WG_QUERIES + wave * 32 + 16 * j + (lane >> 2);
+            int qi = g * WGQ + wave * 32 + 16 * j + (lane >> 2);
             if (qi > nq - 1) qi = nq - 1;
             const unsigned off = (unsigned)qi * 64u + (unsigned)(lane & 3) * 16u;
             const unsigned dst = __builtin_amdgcn_readfirstlane(tau_lds + j * 1024);
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void k_scan(const ScanArgs A) {
             } else {
                 // J > 16 (k > 116): synchronous loads, rarely, staggered between the two waves of a
                 // SIMD (waves 4-7 one tile later) so the partner keeps the matrix pipe busy meanwhile.
-                const int ii = i - (wave >= 4 ? 1 : 0);
+                const int ii = i - (wave >= 4 ? 1 : 0);        // (NW == 4: no SIMD partner, nothing to stagger)
                 if (ii >= 2 && (ii <= 8 || (ii & (ii - 1)) == 0 || (ii & 15) == 0)) set_tau(tau_ord());
             }
             publish();      // completes under this tile's MFMAs
@@ -415,7 +418,8 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     ScanPlan p;
     const int rb = d * elem_bytes(dtype);
-    p.G = (int)((nq + WG_QUERIES - 1) / WG_QUERIES);
+    const int wgq = rb == 1024 ? 128 : WG_QUERIES;      // queries per workgroup (k_scan's NW * 32)
+    p.G = (int)((nq + wgq - 1) / wgq);
     // 128-row tiles (one barrier per 128 rows) for long splits; 64-row tiles keep the split
     // granularity (and the once-repeated bootstrap tile) small when a split is only a few tiles.
     int tr = rb <= 512 ? 128 : 64;
@@ -450,17 +454,17 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     return p;
 }
 
-template <int RB, int TR, int DT>
+template <int RB, int TR, int DT, int NW = 8>
 static int launch_one(const ScanArgs& a, hipStream_t st) {
-    const size_t lds = 2 * (size_t)TR * RB + 8 * 2048;       // two tile buffers + the threshold-slot staging
+    const size_t lds = 2 * (size_t)TR * RB + NW * 2048;      // two tile buffers + the threshold-slot staging
     static bool attr_done[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<RB, TR, DT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<RB, TR, DT, NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((k_scan<RB, TR, DT>), dim3(a.S * a.G), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((k_scan<RB, TR, DT, NW>), dim3(a.S * a.G), dim3(NW * 64), lds, st, a);
     return check_launch("k_scan");
 }
 
@@ -469,11 +473,11 @@ int launch_scan(int dtype, int d, int tile_rows, const ScanArgs& a, hipStream_t 
     if (dtype == DT_F32) {
         if (rb == 256) return launch_one<256, 128, DT_F32>(a, st);
         if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_F32>(a, st) : launch_one<512, 64, DT_F32>(a, st);
-        if (rb == 1024) return launch_one<1024, 64, DT_F32>(a, st);
+        if (rb == 1024) return launch_one<1024, 64, DT_F32, 4>(a, st);
     } else {
         if (rb == 256) return launch_one<256, 128, DT_BF16>(a, st);
         if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_BF16>(a, st) : launch_one<512, 64, DT_BF16>(a, st);
-        if (rb == 1024) return launch_one<1024, 64, DT_BF16>(a, st);
+        if (rb == 1024) return launch_one<1024, 64, DT_BF16, 4>(a, st);
     }
     set_error("scan: unsupported row size %d bytes", rb);
     return SSS_EINVAL;
