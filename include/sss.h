@@ -56,12 +56,17 @@ int sss_f32_to_bf16(const float* x, int64_t count, uint16_t* y, void* stream);
  * incremented once per unproven query (never reset here), so a caller can run many batches
  * without a host sync and check once.  corpus_max_norm = max row 2-norm of the corpus (for
  * the error bound).  workspace: 256-byte aligned, sss_ip_topk_workspace_bytes() bytes (0 = shape
- * not supported by the fused path). */
+ * not supported by the fused path), contents irrelevant.  state: sss_ip_topk_state_bytes(nq) bytes,
+ * 16-byte aligned, ZERO before the first call; every successful call hands it back zeroed (the
+ * kernels clear the words they used), so a search is two launches and no memset.  One state buffer
+ * serves any (n, k, dtype) with nq at most the size it was made for; it must not be shared by
+ * searches in flight on different streams. */
+size_t sss_ip_topk_state_bytes(int64_t nq);
 size_t sss_ip_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k, int dtype);
 int sss_ip_topk(const void* q, int64_t nq, const void* corpus, int64_t n, int d, int k, int dtype,
                 int64_t id_offset, float corpus_max_norm, float* D_out, int64_t* I_out,
-                int32_t* status, int32_t* unproven_count, void* workspace, size_t workspace_bytes,
-                void* stream);
+                int32_t* status, int32_t* unproven_count, void* state, size_t state_bytes,
+                void* workspace, size_t workspace_bytes, void* stream);
 
 /* Exhaustive exact search for a (small) set of queries: qsel [nsel] int32 are the query rows of
  * q to process; results are written to rows qsel[i] of D_out / I_out.  Any n, any d % 4 == 0

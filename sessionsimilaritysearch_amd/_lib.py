@@ -24,8 +24,9 @@ _SIGNATURES = {
     "sss_row_norm_max": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "sss_f32_to_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "sss_ip_topk_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
+    "sss_ip_topk_state_bytes": (c_size_t, [c_int64]),
     "sss_ip_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_float,
-                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "sss_ip_topk_exhaustive_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sss_ip_topk_exhaustive": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                        c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t,

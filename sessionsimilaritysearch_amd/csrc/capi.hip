@@ -27,7 +27,8 @@ int check_launch(const char* what) {
 
 // implemented in the kernel translation units
 size_t ip_topk_workspace_bytes(long nq, long n, int d, int k, int dtype);
-int ip_topk(const void*, long, const void*, long, int, int, int, long, float, float*, long*, int*, int*, void*,
+size_t ip_topk_state_bytes(long nq);
+int ip_topk(const void*, long, const void*, long, int, int, int, long, float, float*, long*, int*, int*, void*, size_t, void*,
             size_t, hipStream_t);
 int topk_merge(const float*, long, const long*, long, int, long, int, float*, long*, hipStream_t);
 int profile_enable(int);
@@ -106,14 +107,16 @@ int sss_row_norm_max(const void* x, int64_t n, int d, int dtype, float* out, voi
 int sss_f32_to_bf16(const float* x, int64_t count, uint16_t* y, void* stream) {
     return sss::f32_to_bf16(x, count, y, ST(stream));
 }
+size_t sss_ip_topk_state_bytes(int64_t nq) { return sss::ip_topk_state_bytes(nq); }
 size_t sss_ip_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k, int dtype) {
     return sss::ip_topk_workspace_bytes(nq, n, d, k, dtype);
 }
 int sss_ip_topk(const void* q, int64_t nq, const void* corpus, int64_t n, int d, int k, int dtype, int64_t id_offset,
                 float corpus_max_norm, float* D_out, int64_t* I_out, int32_t* status, int32_t* unproven_count,
-                void* workspace, size_t workspace_bytes, void* stream) {
+                void* state, size_t state_bytes, void* workspace, size_t workspace_bytes, void* stream) {
     return sss::ip_topk(q, nq, corpus, n, d, k, dtype, id_offset, corpus_max_norm, D_out,
-                        reinterpret_cast<long*>(I_out), status, unproven_count, workspace, workspace_bytes, ST(stream));
+                        reinterpret_cast<long*>(I_out), status, unproven_count, state, state_bytes, workspace,
+                        workspace_bytes, ST(stream));
 }
 size_t sss_ip_topk_exhaustive_workspace_bytes(int64_t nsel, int64_t n) {
     return sss::ip_topk_exhaustive_workspace_bytes(nsel, n);

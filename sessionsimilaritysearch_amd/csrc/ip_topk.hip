@@ -1,4 +1,5 @@
-// Host orchestration of sss_ip_topk: plan -> zero the per-call words -> k_scan -> k_select_*.
+// Host orchestration of sss_ip_topk: plan -> k_scan -> k_select_* (two launches; the per-query state
+// words are handed back zeroed by the select kernel, so there is no per-call memset).
 // (reference call site: `D, I = index.search(normalize(emb), K)`, test_amazon_filterd.py:578.)
 #include "scan.h"
 
@@ -50,14 +51,16 @@ static bool fused_shape_ok(int d, int dtype) {
     return (dtype == DT_F32 || dtype == DT_BF16) && (rb == 256 || rb == 512 || rb == 1024);
 }
 
+size_t ip_topk_state_bytes(long nq) { return nq > 0 ? (size_t)nq * STATE_WORDS * 4 : 0; }
+
 size_t ip_topk_workspace_bytes(long nq, long n, int d, int k, int dtype) {
     if (nq <= 0 || n <= 0 || k <= 0 || !fused_shape_ok(d, dtype)) return 0;
     return make_plan(nq, n, d, k, dtype).total_bytes;
 }
 
 int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dtype, long id_offset,
-            float corpus_max_norm, float* D_out, long* I_out, int* status, int* unproven_count, void* ws,
-            size_t ws_bytes, hipStream_t st) {
+            float corpus_max_norm, float* D_out, long* I_out, int* status, int* unproven_count, void* state,
+            size_t state_bytes, void* ws, size_t ws_bytes, hipStream_t st) {
     if (nq <= 0 || n <= 0 || k <= 0) { set_error("ip_topk: nq, n, k must be positive"); return SSS_EINVAL; }
     if (!fused_shape_ok(d, dtype)) {
         set_error("ip_topk: need dtype 0 (f32, d in {64,128,256}) or 1 (bf16, d in {128,256,512}); got dtype %d d %d", dtype, d);
@@ -65,33 +68,36 @@ int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dty
     }
     if (n >= (1L << 31) - 1024 || nq >= (1L << 31)) { set_error("ip_topk: n and nq must be < 2^31 per shard"); return SSS_EINVAL; }
     if (k > 500) { set_error("ip_topk: k too large (max 500)"); return SSS_EINVAL; }
-    if (reinterpret_cast<uintptr_t>(ws) & 255) { set_error("ip_topk: workspace must be 256-byte aligned"); return SSS_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(ws) & 255) || (reinterpret_cast<uintptr_t>(state) & 15)) {
+        set_error("ip_topk: workspace must be 256-byte aligned, state 16-byte aligned");
+        return SSS_EINVAL;
+    }
+    if (!state || state_bytes < ip_topk_state_bytes(nq)) { set_error("ip_topk: state %zu < %zu bytes", state_bytes, ip_topk_state_bytes(nq)); return SSS_EWORKSPACE; }
     const ScanPlan p = make_plan(nq, n, d, k, dtype);
     if (ws_bytes < p.total_bytes) { set_error("ip_topk: workspace %zu < %zu", ws_bytes, p.total_bytes); return SSS_EWORKSPACE; }
     char* w = reinterpret_cast<char*>(ws);
-    if (hipMemsetAsync(w + p.zero_begin, 0, p.zero_bytes, st) != hipSuccess) { set_error("ip_topk: memset failed"); return SSS_EHIP; }
 
     ScanArgs a;
     a.Q = q; a.C = c; a.nq = (int)nq; a.n = (int)n;
     a.tiles_per_split = p.tiles_per_split; a.total_tiles = p.total_tiles;
     a.S = p.S; a.G = p.G; a.J = p.J; a.cert = p.cert; a.boot = p.boot; a.cap = p.cap;
-    a.slots = reinterpret_cast<unsigned*>(w + p.off_slots);
-    a.cnt = reinterpret_cast<unsigned*>(w + p.off_cnt);
-    a.maxlast = reinterpret_cast<unsigned long long*>(w + p.off_maxlast);
-    a.cand = reinterpret_cast<unsigned long long*>(w + p.off_cand);
+    a.state = reinterpret_cast<unsigned*>(state);
+    a.cand = reinterpret_cast<unsigned long long*>(w);
     Prof& pr = g_prof[current_device()];
     const bool prof = pr.on && pr.n < PROF_RING;
     if (prof) (void)hipEventRecord(pr.ev[2 * pr.n], st);
     int rc = launch_scan(dtype, d, p.tile_rows, a, st);
     if (prof) { (void)hipEventRecord(pr.ev[2 * pr.n + 1], st); ++pr.n; }
-    if (rc) return rc;
+    if (rc) return rc;                 // nothing ran: the state is still clean
 
     SelectArgs s;
     s.Q = q; s.C = c; s.nq = (int)nq; s.d = d; s.dtype = dtype; s.k = k; s.K2 = p.K2; s.J = p.J; s.cap = p.cap;
-    s.cand = a.cand; s.cnt = a.cnt; s.maxlast = a.maxlast; s.slots = a.slots;
+    s.cand = a.cand; s.state = a.state;
     s.id_offset = id_offset; s.corpus_max_norm = corpus_max_norm;
     s.D_out = D_out; s.I_out = I_out; s.status = status; s.unproven_count = unproven_count;
-    return launch_select(s, st);
+    rc = launch_select(s, st);
+    if (rc) (void)hipMemsetAsync(state, 0, ip_topk_state_bytes(nq), st);   // the scan dirtied it and nobody will clear it
+    return rc;
 }
 
 }  // namespace sss

@@ -15,15 +15,20 @@ constexpr unsigned ORD_NEG_INF = 0x007FFFFFu;   // f2ord(-inf); slot value 0 = "
 
 static inline int elem_bytes(int dtype) { return dtype == DT_BF16 ? 2 : 4; }
 
-// Per-search plan (host).  Workspace layout (all offsets 256-byte aligned):
-//   cand    u64 [nq][cap]   compacted candidate keys, cap = L * KP
-//   slots   u32 [nq][J]     admission-threshold slots (zeroed per call)
-//   cnt     u32 [nq]        candidates written per query (zeroed per call)
-//   maxlast u64 [nq]        largest tail key over FULL lane lists (zeroed per call)
+// Per-query STATE words (caller-owned, zero before the first call; every call leaves them zero:
+// the select kernel, their last reader, clears them -- no per-call memset launch):
+//   word 0 .. MAX_SLOTS-1   admission-threshold slots (J used)
+//   word MAX_SLOTS          candidates written for the query
+//   words MAX_SLOTS+2, +3   u64: largest tail key over FULL lane lists
+// The layout depends on nothing but the query index, so one buffer serves every (n, k, dtype).
+constexpr int STATE_WORDS = MAX_SLOTS + 4;
+constexpr int STATE_CNT = MAX_SLOTS, STATE_MAXLAST = MAX_SLOTS + 2;
+
+// Per-search plan (host).  Workspace: cand u64 [nq][cap] compacted candidate keys, cap = L * KP.
 struct ScanPlan {
     int G, S, L, K2, J, cert, boot, tile_rows;
     int total_tiles, tiles_per_split, cap;
-    size_t off_cand, off_slots, off_cnt, off_maxlast, zero_begin, zero_bytes, total_bytes;
+    size_t total_bytes;
 };
 
 ScanPlan make_plan(long nq, long n, int d, int k, int dtype);
@@ -32,9 +37,7 @@ struct ScanArgs {
     const void* Q;
     const void* C;
     int nq, n, tiles_per_split, total_tiles, S, G, J, cert, boot, cap;
-    unsigned* slots;
-    unsigned* cnt;
-    unsigned long long* maxlast;
+    unsigned* state;                // [nq][STATE_WORDS]
     unsigned long long* cand;
 };
 
@@ -45,9 +48,7 @@ struct SelectArgs {
     const void* C;
     int nq, d, dtype, k, K2, J, cap;
     const unsigned long long* cand;
-    const unsigned* cnt;
-    const unsigned long long* maxlast;
-    const unsigned* slots;
+    unsigned* state;                // read, then cleared
     long id_offset;
     float corpus_max_norm;
     float* D_out;

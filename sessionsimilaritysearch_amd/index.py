@@ -115,6 +115,7 @@ class FlatIndex:
         self._cmax_t = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._cmax = None
         self._ws = None
+        self._state = None              # per-query state words of sss_ip_topk: zeroed once, kept zero by the kernels
         self.id_offset = 0              # global id of row 0 (row-sharded corpora)
         self.last_fallback_queries = 0  # queries of the last search() re-run exhaustively
 
@@ -196,10 +197,16 @@ class FlatIndex:
             D, I, status = out
         nbytes = L.sss_ip_topk_workspace_bytes(nq, n, self.d, k, DTYPE_CODE[self.dtype])
         ws = self._workspace(nbytes)
+        sbytes = L.sss_ip_topk_state_bytes(nq)
+        if self._state is None or self._state.numel() < sbytes:
+            self._state = torch.zeros(sbytes, dtype=torch.uint8, device=self.device)
         rc = L.sss_ip_topk(q.data_ptr(), nq, self._xb.data_ptr(), n, self.d, k, DTYPE_CODE[self.dtype], self.id_offset,
                            self.corpus_max_norm(), D.data_ptr(), I.data_ptr(), status.data_ptr(),
                            0 if unproven_count is None else unproven_count.data_ptr(),
+                           self._state.data_ptr(), self._state.numel(),
                            ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
+        if rc != 0:
+            self._state = None          # re-made (zeroed) on the next call
         _lib.check(rc, "sss_ip_topk")
         return D, I, status
 
