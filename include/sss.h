@@ -196,6 +196,19 @@ int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64
                        int64_t n_clicks, int64_t n_graphs, int d, int normalize, float eps, int reduce_sum,
                        float* out, int64_t ld_out, void* stream);
 
+/* The same pooling without materialising the expanded rows (what the fused encoder uses: 7 launches
+ * per forward).  A linear map of an expanded row [tanh(lin[src]) ; tanh(pos_emb[pid])] is a per-node
+ * part plus a per-position table entry, so the caller prepares (weights only) tanhpos = tanh(pos_emb)
+ * [p, p], a2tab = tanhpos Wn[:, d_lin:]^T + bn [p, d], c2tab = tanhpos Wc[:, d_lin:]^T [p, d], and per
+ * batch t = tanh(lin) [np + nq, >= d_lin] (products first, then queries; sss_linear_grouped with the
+ * tanh epilogue) and ac = t [Wn[:, :d_lin] ; Wc[:, :d_lin]]^T [np + nq, 2 d].  Then per graph:
+ * out = mean_e(row_e * (watt . sigmoid(A1[src] + a2tab[pid] + mean_e'(C1[src'] + c2tab[pid'])))). */
+int sss_pool_attention_tab(const float* t, int64_t ld_t, const float* ac, int64_t ld_ac, const float* tanhpos,
+                           const float* a2tab, const float* c2tab, const float* watt, const int32_t* src_row,
+                           const int32_t* pos_id, const int32_t* pptr, const int32_t* qptr, int64_t n_clicks,
+                           int64_t np, int64_t n_graphs, int d_lin, int p, int normalize, float eps,
+                           float* out, int64_t ld_out, void* stream);
+
 /* ---- other conv / pool variants of the reference on the same CSR / segment layout (d <= 256):
  * csr_mean: out[i] = mean over the incoming edges of target i of x[col[e]] (0 without edges) -- the
  *   aggregation of PyG SAGEConv (model/gnn.py:89-121).

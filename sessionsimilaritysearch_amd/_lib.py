@@ -67,6 +67,9 @@ _SIGNATURES = {
                                      c_int64, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "sss_pool_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_int64, c_int, c_int, c_float, c_int, c_void_p, c_int64, c_void_p]),
+    "sss_pool_attention_tab": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_float,
+                                       c_void_p, c_int64, c_void_p]),
     "sss_csr_mean": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "sss_segment_reduce": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "sss_attention_dot_pool": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),

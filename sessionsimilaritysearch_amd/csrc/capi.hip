@@ -70,6 +70,8 @@ int pool_expand_mean(const float*, const float*, long, const int*, const int*, c
                      const float*, float*, long, float*, long, hipStream_t);
 int pool_attention(const float*, long, const float*, long, const float*, long, const float*, const int*, const int*, long, long,
                    int, int, float, int, float*, long, hipStream_t);
+int pool_attention_tab(const float*, long, const float*, long, const float*, const float*, const float*, const float*, const int*,
+                       const int*, const int*, const int*, long, long, long, int, int, int, float, float*, long, hipStream_t);
 int csr_mean(const float*, long, const int*, const int*, long, int, float*, long, hipStream_t);
 int segment_reduce(const float*, long, const float*, const int*, long, int, int, float*, long, hipStream_t);
 int attention_dot_pool(const float*, long, const int*, long, int, float*, long, hipStream_t);
@@ -205,6 +207,13 @@ int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64
                        int d, int normalize, float eps, int reduce_sum, float* out, int64_t ld_out, void* stream) {
     return sss::pool_attention(node, ld_node, a, ld_a, b, ld_b, watt, pptr, qptr, n_clicks, n_graphs, d, normalize, eps,
                                reduce_sum, out, ld_out, ST(stream));
+}
+int sss_pool_attention_tab(const float* t, int64_t ld_t, const float* ac, int64_t ld_ac, const float* tanhpos, const float* a2tab,
+                           const float* c2tab, const float* watt, const int32_t* src_row, const int32_t* pos_id,
+                           const int32_t* pptr, const int32_t* qptr, int64_t n_clicks, int64_t np, int64_t n_graphs, int d_lin,
+                           int p, int normalize, float eps, float* out, int64_t ld_out, void* stream) {
+    return sss::pool_attention_tab(t, ld_t, ac, ld_ac, tanhpos, a2tab, c2tab, watt, src_row, pos_id, pptr, qptr, n_clicks, np,
+                                   n_graphs, d_lin, p, normalize, eps, out, ld_out, ST(stream));
 }
 int sss_csr_mean(const float* x, int64_t ld_x, const int32_t* rowptr, const int32_t* col, int64_t n_dst, int d, float* out,
                  int64_t ld_out, void* stream) {

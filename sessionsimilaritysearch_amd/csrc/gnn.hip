@@ -785,6 +785,112 @@ __global__ __launch_bounds__(256) void k_pool_attention(const float* __restrict_
     if (live) *reinterpret_cast<float4*>(out + g * ld_out + c4) = acc;
 }
 
+// PositionalAttentionPooling without materialising the expanded rows (3 launches instead of 4).
+// An expanded row e is [tanh(lin[src(e)]) ; tanh(pos_emb[pid(e)])]: every LINEAR map of it splits into
+// a per-NODE part and a per-POSITION table entry,
+//     node_emb_lin(row e)   = A1[src(e)] + A2tab[pid(e)]      A1 = T Wn[:, :Dl]^T,  A2tab = tanh(P) Wn[:, Dl:]^T + bn
+//     coarse_rep_lin(row e) = C1[src(e)] + C2tab[pid(e)]      C1 = T Wc[:, :Dl]^T,  C2tab = tanh(P) Wc[:, Dl:]^T
+// with T = tanh(lin) per node (GEMM epilogue).  coarse_rep_lin of the graph MEAN is the mean of the
+// rows' images, so one lane group per graph needs two passes over its rows and no [n_exp, D] buffers:
+//   pass 1: bc = mean_e(C1[src] + C2tab[pid])
+//   pass 2: att_e = watt . sigmoid(A1[src] + A2tab[pid] + bc);  out = mean_e(row_e * att_e)  (+ normalise)
+// T / AC rows: products [0, Np), queries [Np, Np + Nq).  AC = [A1 | C1], 2D wide.
+// One WAVE per graph: LPR lanes own the float4 columns of a row, the wave's 64 / LPR row slots take
+// rows slot, slot + RS, ...; the (row -> node, position) indices of the whole graph are loaded once,
+// one row per lane, and broadcast with shuffles, so both passes issue their gathers without a
+// dependent index load in front.
+template <int LPR>
+__global__ __launch_bounds__(256) void k_pool_attention_tab(const float* __restrict__ T, long ld_t, const float* __restrict__ AC,
+                                                            long ld_ac, const float* __restrict__ tanhpos,
+                                                            const float* __restrict__ A2tab, const float* __restrict__ C2tab,
+                                                            const float* __restrict__ watt, const int* __restrict__ src_row,
+                                                            const int* __restrict__ pos_id, const int* __restrict__ pptr,
+                                                            const int* __restrict__ qptr, long n_clicks, long Np,
+                                                            long n_graphs, int Dl, int P, int normalize, float eps,
+                                                            float* __restrict__ out, long ld_out) {
+    constexpr int RS = 64 / LPR;                                 // row slots per wave
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR, slot = lane / LPR;
+    const long g = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (g >= n_graphs) return;                                   // whole wave
+    const int D = Dl + P, c4 = sub * 4;
+    const bool colok = c4 < D;
+    const int p0 = pptr[g], p1 = pptr[g + 1], q0 = qptr[g], q1 = qptr[g + 1];
+    const int np_ = p1 - p0, cnt = np_ + (q1 - q0);
+    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    float4 bc = make_float4(0.f, 0.f, 0.f, 0.f), acc = bc, w4 = bc;
+    if (colok) w4 = *reinterpret_cast<const float4*>(watt + c4);
+    for (int base = 0; base < cnt; base += 64) {                 // graphs longer than 64 rows: chunks (bc needs all rows first)
+        const int t_l = base + lane;
+        int my_node = 0, my_pid = 0;
+        if (t_l < cnt) {
+            const long e = t_l < np_ ? (long)(p0 + t_l) : n_clicks + (long)(q0 + t_l - np_);
+            my_node = (int)((t_l < np_ ? 0 : Np) + src_row[e]);
+            my_pid = pos_id[e];
+        }
+        const int nrow = min(64, cnt - base);
+        for (int r0 = 0; r0 < nrow; r0 += RS) {                  // pass 1 (this chunk): sum of C1[node] + C2tab[pid]
+            const int r = r0 + slot;
+            const int node = __shfl(my_node, r & 63), pid = __shfl(my_pid, r & 63);
+            if (r < nrow && colok) {
+                const float4 v = *reinterpret_cast<const float4*>(AC + (long)node * ld_ac + D + c4);
+                const float4 w = *reinterpret_cast<const float4*>(C2tab + (long)pid * D + c4);
+                bc.x += v.x + w.x; bc.y += v.y + w.y; bc.z += v.z + w.z; bc.w += v.w + w.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {                         // combine the row slots
+        bc.x += __shfl_xor(bc.x, o); bc.y += __shfl_xor(bc.y, o); bc.z += __shfl_xor(bc.z, o); bc.w += __shfl_xor(bc.w, o);
+    }
+    bc.x *= inv; bc.y *= inv; bc.z *= inv; bc.w *= inv;
+    for (int base = 0; base < cnt; base += 64) {                 // pass 2: attention-weighted sum
+        const int t_l = base + lane;
+        int my_node = 0, my_pid = 0;
+        if (t_l < cnt) {
+            const long e = t_l < np_ ? (long)(p0 + t_l) : n_clicks + (long)(q0 + t_l - np_);
+            my_node = (int)((t_l < np_ ? 0 : Np) + src_row[e]);
+            my_pid = pos_id[e];
+        }
+        const int nrow = min(64, cnt - base);
+        for (int r0 = 0; r0 < nrow; r0 += RS) {
+            const int r = r0 + slot;
+            const int node = __shfl(my_node, r & 63), pid = __shfl(my_pid, r & 63);
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            float part = 0.f;
+            if (r < nrow && colok) {
+                const float4 a1 = *reinterpret_cast<const float4*>(AC + (long)node * ld_ac + c4);
+                const float4 a2 = *reinterpret_cast<const float4*>(A2tab + (long)pid * D + c4);
+                float xv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c4 + j;
+                    xv[j] = c < Dl ? T[(long)node * ld_t + c] : tanhpos[(long)pid * P + (c - Dl)];
+                }
+                x = make_float4(xv[0], xv[1], xv[2], xv[3]);
+                part = w4.x * sigmoidf_(a1.x + a2.x + bc.x) + w4.y * sigmoidf_(a1.y + a2.y + bc.y) +
+                       w4.z * sigmoidf_(a1.z + a2.z + bc.z) + w4.w * sigmoidf_(a1.w + a2.w + bc.w);
+            }
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) part += __shfl_xor(part, o);
+            acc = f4_fma(part, x, acc);
+        }
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+    }
+    acc.x *= inv; acc.y *= inv; acc.z *= inv; acc.w *= inv;
+    if (normalize) {
+        float ss = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        const float den = sqrtf(fmaxf(ss, eps));
+        acc.x /= den; acc.y /= den; acc.z /= den; acc.w /= den;
+    }
+    if (slot == 0 && colok) *reinterpret_cast<float4*>(out + g * ld_out + c4) = acc;
+}
+
 // ------------------------------------------------------------------------------ host launchers
 int linear_grouped(LinBatch& b, hipStream_t st) {
     if (b.nprob < 1 || b.nprob > 4 || b.K <= 0 || b.K % 32) { set_error("linear_grouped: 1..4 problems, K %% 32 == 0"); return SSS_EINVAL; }
@@ -855,6 +961,24 @@ int pool_attention(const float* node, long ld_node, const float* Aa, long ld_a, 
                                            ld_node, Aa, ld_a, Bc, ld_b, watt, pptr, qptr, n_clicks, n_graphs, D, normalize, eps,
                                            reduce_sum, out, ld_out));
     return check_launch("k_pool_attention");
+}
+
+int pool_attention_tab(const float* T, long ld_t, const float* AC, long ld_ac, const float* tanhpos, const float* A2tab,
+                       const float* C2tab, const float* watt, const int* src_row, const int* pos_id, const int* pptr,
+                       const int* qptr, long n_clicks, long Np, long n_graphs, int Dl, int P, int normalize, float eps, float* out,
+                       long ld_out, hipStream_t st) {
+    const int D = Dl + P;
+    if (n_graphs < 0 || Dl <= 0 || P < 0 || D % 4 || D > 256 || ld_t < Dl || ld_ac % 4 || ld_ac < 2 * D || ld_out % 4 || ld_out < D) {
+        set_error("pool_attention_tab: need (Dl + P) %% 4 == 0, <= 256, ld_ac >= 2 (Dl + P), 16-byte aligned row strides");
+        return SSS_EINVAL;
+    }
+    if (n_graphs == 0) return SSS_OK;
+    const int lpr = lanes_for(D);
+    const long per = 4;                                          // one wave per graph
+    SSS_LPR_SWITCH(lpr, hipLaunchKernelGGL(k_pool_attention_tab<L>, dim3((unsigned)((n_graphs + per - 1) / per)), dim3(256), 0, st, T,
+                                           ld_t, AC, ld_ac, tanhpos, A2tab, C2tab, watt, src_row, pos_id, pptr, qptr, n_clicks, Np,
+                                           n_graphs, Dl, P, normalize, eps, out, ld_out));
+    return check_launch("k_pool_attention_tab");
 }
 
 }  // namespace sss
