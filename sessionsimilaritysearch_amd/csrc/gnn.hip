@@ -468,7 +468,8 @@ template <int KC>
 __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
     constexpr int CPR = KC / 4;
     constexpr int NLD = LT * CPR / 256;
-    constexpr int RS = CPR < 16 ? 16 : CPR;     // LDS row stride in 16-byte chunks (the XOR swizzle spans 16)
+    constexpr int RS = CPR;                     // LDS row stride in 16-byte chunks
+    constexpr int SW = RS < 16 ? RS - 1 : 15;   // XOR swizzle mask (stays inside the row)
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     float* lx = lds_raw;
     float* lw = lds_raw + LT * RS * 4;
@@ -521,20 +522,20 @@ __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
         for (int i = 0; i < NLD; ++i) {
             const int p = tid + 256 * i;
             const int tr = p / CPR, c = p % CPR;
-            const int cs = c ^ (tr & 15);
+            const int cs = c ^ (tr & SW);
             *reinterpret_cast<f32x4*>(lx + (tr * RS + cs) * 4) = sx[i];
             *reinterpret_cast<f32x4*>(lw + (tr * RS + cs) * 4) = sw[i];
         }
         __syncthreads();
         if (k0 + KC < K) fetch(k0 + KC);                     // next chunk's loads fly under this chunk's MFMAs
-        float4 a = *reinterpret_cast<const float4*>(lx + (xr * RS + (h ^ (xr & 15))) * 4);
-        float4 b = *reinterpret_cast<const float4*>(lw + (wrow * RS + (h ^ (wrow & 15))) * 4);
+        float4 a = *reinterpret_cast<const float4*>(lx + (xr * RS + (h ^ (xr & SW))) * 4);
+        float4 b = *reinterpret_cast<const float4*>(lw + (wrow * RS + (h ^ (wrow & SW))) * 4);
 #pragma unroll
         for (int u = 0; u < KC / 8; ++u) {
             float4 na = a, nb = b;
             if (u + 1 < KC / 8) {
-                na = *reinterpret_cast<const float4*>(lx + (xr * RS + ((2 * u + 2 + h) ^ (xr & 15))) * 4);
-                nb = *reinterpret_cast<const float4*>(lw + (wrow * RS + ((2 * u + 2 + h) ^ (wrow & 15))) * 4);
+                na = *reinterpret_cast<const float4*>(lx + (xr * RS + ((2 * u + 2 + h) ^ (xr & SW))) * 4);
+                nb = *reinterpret_cast<const float4*>(lw + (wrow * RS + ((2 * u + 2 + h) ^ (wrow & SW))) * 4);
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
@@ -908,11 +909,11 @@ int linear_grouped(LinBatch& b, hipStream_t st) {
     }
     for (int i = b.nprob; i < 4; ++i) { b.p[i] = b.p[0]; b.p[i].tile_begin = 0x7fffffff; }
     if (total == 0) return SSS_OK;
-    // K chunks of 64: 32 KiB of LDS per workgroup, so up to five workgroups share a CU and their
-    // load / MFMA / store phases overlap (these launches are latency-bound, not FLOP-bound)
-    const int lds64 = 2 * LT * 16 * 16;
-    if (b.K % 64 == 0) hipLaunchKernelGGL(k_linear_grouped<64>, dim3((unsigned)total), dim3(256), lds64, st, b);
-    else hipLaunchKernelGGL(k_linear_grouped<32>, dim3((unsigned)total), dim3(256), lds64, st, b);
+    // K chunks of 32: 16 KiB of LDS per workgroup, so eight workgroups share a CU, the whole grid of a
+    // query-batch launch is resident at once and the load / MFMA / store phases of different workgroups
+    // overlap (these launches are latency-bound, not FLOP-bound; measured against 64- and 128-chunks)
+    const int lds32 = 2 * LT * 8 * 16;
+    hipLaunchKernelGGL(k_linear_grouped<32>, dim3((unsigned)total), dim3(256), lds32, st, b);
     return check_launch("k_linear_grouped");
 }
 
