@@ -58,9 +58,9 @@ int sss_f32_to_bf16(const float* x, int64_t count, uint16_t* y, void* stream);
  * the error bound).  workspace: 256-byte aligned, sss_ip_topk_workspace_bytes() bytes (0 = shape
  * not supported by the fused path), contents irrelevant.  state: sss_ip_topk_state_bytes(nq) bytes,
  * 16-byte aligned, ZERO before the first call; every successful call hands it back zeroed (the
- * kernels clear the words they used), so a search is two launches and no memset.  One state buffer
- * serves any (n, k, dtype) with nq at most the size it was made for; it must not be shared by
- * searches in flight on different streams. */
+ * kernels clear the words they used), so a search is two launches and no memset.  Since the
+ * whole buffer is zero between calls, one buffer serves any (nq', n, k, dtype) with nq' at most
+ * the nq it was sized for; it must not be shared by searches in flight on different streams. */
 size_t sss_ip_topk_state_bytes(int64_t nq);
 size_t sss_ip_topk_workspace_bytes(int64_t nq, int64_t n, int d, int k, int dtype);
 int sss_ip_topk(const void* q, int64_t nq, const void* corpus, int64_t n, int d, int k, int dtype,

@@ -51,7 +51,7 @@ static bool fused_shape_ok(int d, int dtype) {
     return (dtype == DT_F32 || dtype == DT_BF16) && (rb == 256 || rb == 512 || rb == 1024);
 }
 
-size_t ip_topk_state_bytes(long nq) { return nq > 0 ? (size_t)nq * STATE_WORDS * 4 : 0; }
+size_t ip_topk_state_bytes(long nq) { return nq > 0 ? state_words(nq) * 4 : 0; }
 
 size_t ip_topk_workspace_bytes(long nq, long n, int d, int k, int dtype) {
     if (nq <= 0 || n <= 0 || k <= 0 || !fused_shape_ok(d, dtype)) return 0;
@@ -81,7 +81,10 @@ int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dty
     a.Q = q; a.C = c; a.nq = (int)nq; a.n = (int)n;
     a.tiles_per_split = p.tiles_per_split; a.total_tiles = p.total_tiles;
     a.S = p.S; a.G = p.G; a.J = p.J; a.cert = p.cert; a.boot = p.boot; a.cap = p.cap;
-    a.state = reinterpret_cast<unsigned*>(state);
+    unsigned* sw = reinterpret_cast<unsigned*>(state);
+    a.slots = sw;
+    a.cnt = sw + state_off_cnt(nq);
+    a.maxlast = reinterpret_cast<unsigned long long*>(sw + state_off_maxlast(nq));
     a.cand = reinterpret_cast<unsigned long long*>(w);
     Prof& pr = g_prof[current_device()];
     const bool prof = pr.on && pr.n < PROF_RING;
@@ -92,7 +95,7 @@ int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dty
 
     SelectArgs s;
     s.Q = q; s.C = c; s.nq = (int)nq; s.d = d; s.dtype = dtype; s.k = k; s.K2 = p.K2; s.J = p.J; s.cap = p.cap;
-    s.cand = a.cand; s.state = a.state;
+    s.cand = a.cand; s.slots = a.slots; s.cnt = a.cnt; s.maxlast = a.maxlast;
     s.id_offset = id_offset; s.corpus_max_norm = corpus_max_norm;
     s.D_out = D_out; s.I_out = I_out; s.status = status; s.unproven_count = unproven_count;
     rc = launch_select(s, st);

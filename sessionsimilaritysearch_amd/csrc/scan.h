@@ -15,14 +15,15 @@ constexpr unsigned ORD_NEG_INF = 0x007FFFFFu;   // f2ord(-inf); slot value 0 = "
 
 static inline int elem_bytes(int dtype) { return dtype == DT_BF16 ? 2 : 4; }
 
-// Per-query STATE words (caller-owned, zero before the first call; every call leaves them zero:
-// the select kernel, their last reader, clears them -- no per-call memset launch):
-//   word 0 .. MAX_SLOTS-1   admission-threshold slots (J used)
-//   word MAX_SLOTS          candidates written for the query
-//   words MAX_SLOTS+2, +3   u64: largest tail key over FULL lane lists
-// The layout depends on nothing but the query index, so one buffer serves every (n, k, dtype).
-constexpr int STATE_WORDS = MAX_SLOTS + 4;
-constexpr int STATE_CNT = MAX_SLOTS, STATE_MAXLAST = MAX_SLOTS + 2;
+// STATE words (caller-owned, zero before the first call; every call leaves them zero: the select
+// kernel, their last reader, clears what the call used -- no per-call memset launch).  Because the
+// whole buffer is zero between calls, each call may lay it out as it likes:
+//   slots   u32 [nq][J]   admission-threshold slots (J = 16: 64 contiguous bytes per query)
+//   cnt     u32 [nq]      candidates written per query        (at word nq * MAX_SLOTS)
+//   maxlast u64 [nq]      largest tail key over FULL lists    (8-byte aligned, after cnt)
+static inline size_t state_off_cnt(long nq) { return (size_t)nq * MAX_SLOTS; }                       // in words
+static inline size_t state_off_maxlast(long nq) { return (state_off_cnt(nq) + (size_t)nq + 1) & ~(size_t)1; }
+static inline size_t state_words(long nq) { return state_off_maxlast(nq) + 2 * (size_t)nq; }
 
 // Per-search plan (host).  Workspace: cand u64 [nq][cap] compacted candidate keys, cap = L * KP.
 struct ScanPlan {
@@ -37,7 +38,9 @@ struct ScanArgs {
     const void* Q;
     const void* C;
     int nq, n, tiles_per_split, total_tiles, S, G, J, cert, boot, cap;
-    unsigned* state;                // [nq][STATE_WORDS]
+    unsigned* slots;                // the three arrays live in the caller's state buffer
+    unsigned* cnt;
+    unsigned long long* maxlast;
     unsigned long long* cand;
 };
 
@@ -48,7 +51,9 @@ struct SelectArgs {
     const void* C;
     int nq, d, dtype, k, K2, J, cap;
     const unsigned long long* cand;
-    unsigned* state;                // read, then cleared
+    unsigned* slots;                // state arrays: read, then cleared
+    unsigned* cnt;
+    unsigned long long* maxlast;
     long id_offset;
     float corpus_max_norm;
     float* D_out;

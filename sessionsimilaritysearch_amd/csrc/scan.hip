@@ -139,8 +139,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     unsigned* my_slot = nullptr;
     const unsigned* my_half = nullptr;
     if (use_tau) {
-        my_slot = A.state + (size_t)q_ld * STATE_WORDS + (unsigned)(2 * split + h) % (unsigned)J;
-        my_half = A.state + (size_t)q_ld * STATE_WORDS + h * (J >> 1);
+        my_slot = A.slots + (size_t)q_ld * J + (unsigned)(2 * split + h) % (unsigned)J;
+        my_half = A.slots + (size_t)q_ld * J + h * (J >> 1);
     }
     // min over the query's J slots.  Synchronous form (bootstrap wait; J > 16): each lane of the
     // (h = 0, 1) pair reads half, 8 slots a step, with agent-scope loads.
@@ -159,12 +159,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         for (int j = 0; j < 2; ++j) {
             int qi = g * WGQ + wave * 32 + 16 * j + (lane >> 2);
             if (qi > nq - 1) qi = nq - 1;
-            const unsigned off = (unsigned)qi * (unsigned)(STATE_WORDS * 4) + (unsigned)(lane & 3) * 16u;
+            const unsigned off = (unsigned)qi * 64u + (unsigned)(lane & 3) * 16u;
             const unsigned dst = __builtin_amdgcn_readfirstlane(tau_lds + j * 1024);
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                          "global_load_lds_dwordx4 %1, %3 sc1\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(off), "s"(dst), "s"(A.state) : "memory");
+                         : "=&s"(keep) : "v"(off), "s"(dst), "s"(A.slots) : "memory");
         }
     };
     auto tau_read = [&]() -> unsigned {
@@ -388,14 +388,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
 #pragma unroll
         for (int i = 0; i < KP; ++i) nreal += li[i] >= 0 ? 1 : 0;
         if (nreal > 0) {
-            unsigned* st = A.state + (size_t)q_glob * STATE_WORDS;
-            const unsigned base = atomicAdd(st + STATE_CNT, (unsigned)nreal);
+            const unsigned base = atomicAdd(A.cnt + q_glob, (unsigned)nreal);
             unsigned long long* dst = A.cand + (size_t)q_glob * A.cap + base;
 #pragma unroll
             for (int i = 0; i < KP; ++i)
                 if (i < nreal) dst[i] = make_key(ls[i], li[i]);
-            if (nreal == KP)
-                atomicMax(reinterpret_cast<unsigned long long*>(st + STATE_MAXLAST), (unsigned long long)make_key(ls[KP - 1], li[KP - 1]));
+            if (nreal == KP) atomicMax(A.maxlast + q_glob, (unsigned long long)make_key(ls[KP - 1], li[KP - 1]));
         }
     }
 }

@@ -90,9 +90,9 @@ __device__ __forceinline__ double err_bound(int d, int dtype, double qnorm, doub
 }
 
 // Hand the query's state words back zeroed (scan.h: the contract that replaces a per-call memset).
-__device__ __forceinline__ void clear_state(unsigned* st, int J, int t, int nthreads) {
-    for (int j = t; j < J; j += nthreads) st[j] = 0u;
-    if (t == 0) { st[STATE_CNT] = 0u; st[STATE_MAXLAST] = 0u; st[STATE_MAXLAST + 1] = 0u; }
+__device__ __forceinline__ void clear_state(const SelectArgs& A, int q, int t, int nthreads) {
+    for (int j = t; j < A.J; j += nthreads) A.slots[(size_t)q * A.J + j] = 0u;
+    if (t == 0) { A.cnt[q] = 0u; A.maxlast[q] = 0ull; }
 }
 
 // min over the J threshold slots of query q as an ordered-uint (0: some class never published)
@@ -164,11 +164,10 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     const int K2 = A.K2, k = A.k;
     float* Dq = A.D_out + (size_t)q * k;
     long* Iq = A.I_out + (size_t)q * k;
-    unsigned* st_q = A.state + (size_t)q * STATE_WORDS;
-    const int M = (int)st_q[STATE_CNT];
+    const int M = (int)A.cnt[q];
     if (M > FS_CAP) {                                             // adversarial input: let the exhaustive path decide
         if (lane == 0) { A.status[q] = 1; if (A.unproven_count) atomicAdd(A.unproven_count, 1); }
-        clear_state(st_q, A.J, lane, 64);
+        clear_state(A, q, lane, 64);
         return;
     }
     // ---- stage keys and the query row; per-lane best of keys lane, lane+64, ...
@@ -223,10 +222,10 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
         Dq[j] = -3.4028234663852886e38f;
         Iq[j] = -1;
     }
-    const unsigned tau_o = A.J > 0 ? final_tau_ord(st_q, A.J, lane) : 0u;
-    const unsigned long long maxlast = *reinterpret_cast<const unsigned long long*>(st_q + STATE_MAXLAST);
+    const unsigned tau_o = A.J > 0 ? final_tau_ord(A.slots + (size_t)q * A.J, A.J, lane) : 0u;
+    const unsigned long long maxlast = A.maxlast[q];
     wave_sync();                                                  // every lane has read the state words
-    clear_state(st_q, A.J, lane, 64);
+    clear_state(A, q, lane, 64);
     if (lane == 0) {
         const double B = err_bound(A.d, A.dtype, sqrt(qn2), (double)A.corpus_max_norm);
         const int st = decide_status(sel[K2 - 1], maxlast, tau_o, A.J, nvalid, k, *s_kth, B);
@@ -250,8 +249,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
     const int K2 = A.K2, k = A.k;
     float* Dq = A.D_out + (size_t)q * k;
     long* Iq = A.I_out + (size_t)q * k;
-    unsigned* st_q = A.state + (size_t)q * STATE_WORDS;
-    const int M = (int)st_q[STATE_CNT];
+    const int M = (int)A.cnt[q];
     int M2 = 64;
     while (M2 < M || M2 < K2) M2 <<= 1;                            // <= cap_pow2 by construction
     const unsigned long long* ck = A.cand + (size_t)q * A.cap;
@@ -299,10 +297,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
         Iq[j] = -1;
     }
     if (tid < 64) {                                               // wave 0 alone touches the state from here on
-        const unsigned tau_o = A.J > 0 ? final_tau_ord(st_q, A.J, lane) : 0u;
-        const unsigned long long maxlast = *reinterpret_cast<const unsigned long long*>(st_q + STATE_MAXLAST);
+        const unsigned tau_o = A.J > 0 ? final_tau_ord(A.slots + (size_t)q * A.J, A.J, lane) : 0u;
+        const unsigned long long maxlast = A.maxlast[q];
         wave_sync();
-        clear_state(st_q, A.J, lane, 64);
+        clear_state(A, q, lane, 64);
         if (tid == 0) {
             double qq = 0.0;
             for (int w = 0; w < SORT_THREADS / 64; ++w) qq += s_q2[w];
