@@ -414,3 +414,27 @@ def test_hamming_massive_ties(cuda):
     D, I = idx.search(q, 100)
     Dr, Ir = sr.hamming_search(q, codes, 100)
     assert np.array_equal(D, Dr) and np.array_equal(I, Ir)
+
+
+def test_sharded_index_single_rank_engine_and_unproven_counter(cuda):
+    """ShardedFlatIndex + HipEngine as bench.py drives them (world size 1): the asynchronous search
+    counts unproven queries on the device, the synchronous search() repairs them exhaustively."""
+    from sessionsimilaritysearch_amd.distributed import HipEngine, ShardedFlatIndex
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(80)
+    base = _unit(rng, 30, 128)
+    c = np.ascontiguousarray(np.repeat(base, 50, axis=0)[rng.permutation(1500)])     # every row has 49 exact duplicates
+    q = _unit(rng, 20, 128)
+    idx = FlatIndex(128, "ip", cuda)
+    idx.add(c)
+    eng = HipEngine(idx)
+    sh = ShardedFlatIndex(eng, cuda)
+    tq = torch.from_numpy(q).to(cuda)
+    D, I, status = sh.search_async(tq, 10)
+    n_bad = int((status != 0).sum().item())
+    assert n_bad == 20 and int(eng.unproven.item()) == 20           # ties at the boundary everywhere
+    sh.search_async(tq, 10)
+    assert int(eng.unproven.item()) == 40                           # the counter accumulates until the caller resets it
+    D, I = sh.search(tq, 10)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr)
