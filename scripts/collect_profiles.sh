@@ -37,4 +37,6 @@ pmc pmc_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" $PM
 PM5="bench.py --steps 4 --warmup 1 --no-cpu-baseline --corpus-rows 10000000 --corpus-source random --dtype bf16 --d 256 --nq 4096"
 pmc pmc_fetch_c5 FETCH_SIZE $PM5
 pmc pmc_mfma_c5 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" $PM5
+python3 scripts/bench_components.py 2>/dev/null | grep '^{' > "$OUT/components.txt"
+echo "[components] done"
 ls -la "$OUT"

@@ -12,6 +12,8 @@ for name in ("bench_default", "bench_c4_10m", "bench_c5_bf16", "bench_c3", "enco
     lj = f"{src}/{name}_line.json"
     if os.path.exists(lj) and os.path.getsize(lj) > 0:
         shutil.copy(lj, f"{dst}/{tag}_{name}_line.json")
+if os.path.exists(f"{src}/components.txt"):
+    shutil.copy(f"{src}/components.txt", f"{dst}/{tag}_components.txt")
 for name in ("search_shapes", "encoder"):
     lines = [l for l in open(f"{src}/{name}.log") if l.startswith("{") or l.startswith("sessions=")]
     open(f"{dst}/{tag}_{name}_lines.txt", "w").writelines(lines)

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_hamming_scan(const unsigned* __restrict
         const int row0 = t * HT_ROWS;
         const int nrows = min(HT_ROWS, n - row0);
         const unsigned* tl = tile[buf];
-        for (int r = 0; r < nrows; ++r) {
+        auto dist_of = [&](int r) {
             unsigned d = 0;
 #pragma unroll
             for (int w = 0; w < NW; w += 4) {
@@ -79,6 +79,21 @@ __global__ __launch_bounds__(256) void k_hamming_scan(const unsigned* __restrict
                 d += __builtin_popcount(c4.x ^ qw[w]) + __builtin_popcount(c4.y ^ qw[w + 1]) +
                      __builtin_popcount(c4.z ^ qw[w + 2]) + __builtin_popcount(c4.w ^ qw[w + 3]);
             }
+            return d;
+        };
+        int r = 0;
+        for (; r + 4 <= nrows; r += 4) {             // four rows per trip: the LDS broadcasts overlap the popcounts
+            const unsigned d0 = dist_of(r), d1 = dist_of(r + 1), d2 = dist_of(r + 2), d3 = dist_of(r + 3);
+            const unsigned dm = min(min(d0, d1), min(d2, d3));
+            if (__builtin_amdgcn_ballot_w64(dm < ld[HK - 1]) != 0) {     // rare after the first tiles
+                if (d0 < ld[HK - 1]) hlist_insert<HK>(ld, li, d0, row0 + r);
+                if (d1 < ld[HK - 1]) hlist_insert<HK>(ld, li, d1, row0 + r + 1);
+                if (d2 < ld[HK - 1]) hlist_insert<HK>(ld, li, d2, row0 + r + 2);
+                if (d3 < ld[HK - 1]) hlist_insert<HK>(ld, li, d3, row0 + r + 3);
+            }
+        }
+        for (; r < nrows; ++r) {
+            const unsigned d = dist_of(r);
             if (d < ld[HK - 1]) hlist_insert<HK>(ld, li, d, row0 + r);
         }
         buf ^= 1;
