@@ -68,6 +68,21 @@ int sss_ip_topk(const void* q, int64_t nq, const void* corpus, int64_t n, int d,
                 int32_t* status, int32_t* unproven_count, void* state, size_t state_bytes,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same search for a float32 corpus with the scan on the bf16 MFMA ("split" scan, the default of
+ * the Python FlatIndex): corpus_split [n, 2d] bfloat16 is the image sss_split_bf16 makes of the
+ * corpus rows -- [hi(d) | lo(d)], hi = rne_bf16(x), lo = rne_bf16(x - hi), 4 bytes per element like
+ * the f32 row.  The scan scores hi*hi + hi*lo + lo*hi (three bf16 MFMA passes, f32 accumulate:
+ * 16/3 of the f32 MFMA rate) to pick the candidates; the candidates are re-scored from the float32
+ * rows exactly as in sss_ip_topk, and the per-query proof uses the split's own error bound
+ * ((3.03 * 2^-16 + 3d * 2^-23) |q| |c|), so D_out / I_out / status obey the same contract:
+ * identical results for every query with status 0.  q float32 [nq, d]; d in {64,128,256};
+ * workspace: sss_ip_topk_workspace_bytes(nq, n, d, k, 0); state as above. */
+int sss_split_bf16(const float* x, int64_t n, int d, uint16_t* y, void* stream);
+int sss_ip_topk_split(const float* q, int64_t nq, const float* corpus, const uint16_t* corpus_split,
+                      int64_t n, int d, int k, int64_t id_offset, float corpus_max_norm, float* D_out,
+                      int64_t* I_out, int32_t* status, int32_t* unproven_count, void* state,
+                      size_t state_bytes, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Exhaustive exact search for a (small) set of queries: qsel [nsel] int32 are the query rows of
  * q to process; results are written to rows qsel[i] of D_out / I_out.  Any n, any d % 4 == 0
  * (dtype 0) or d % 8 == 0 (dtype 1), k <= 1024.  metric: 0 = inner product, 1 = squared L2

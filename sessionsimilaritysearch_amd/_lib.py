@@ -27,6 +27,10 @@ _SIGNATURES = {
     "sss_ip_topk_state_bytes": (c_size_t, [c_int64]),
     "sss_ip_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_float,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "sss_split_bf16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "sss_ip_topk_split": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_float,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
+                                  c_void_p]),
     "sss_ip_topk_exhaustive_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sss_ip_topk_exhaustive": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                        c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t,

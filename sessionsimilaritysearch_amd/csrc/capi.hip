@@ -30,6 +30,9 @@ size_t ip_topk_workspace_bytes(long nq, long n, int d, int k, int dtype);
 size_t ip_topk_state_bytes(long nq);
 int ip_topk(const void*, long, const void*, long, int, int, int, long, float, float*, long*, int*, int*, void*, size_t, void*,
             size_t, hipStream_t);
+int ip_topk_split(const float*, long, const float*, const void*, long, int, int, long, float, float*, long*, int*, int*, void*,
+                  size_t, void*, size_t, hipStream_t);
+int split_bf16(const float*, long, int, unsigned short*, hipStream_t);
 int topk_merge(const float*, long, const long*, long, int, long, int, float*, long*, hipStream_t);
 int profile_enable(int);
 int profile_read(double*, int*);
@@ -97,7 +100,7 @@ int graph_fill(const long*, const unsigned char*, const long*, const long*, long
 
 extern "C" {
 
-int sss_version(void) { return 200; }
+int sss_version(void) { return 210; }
 const char* sss_last_error(void) { return sss::g_err; }
 
 int sss_normalize_rows(float* x, int64_t n, int d, int64_t ld, float eps, int rule, void* stream) {
@@ -119,6 +122,17 @@ int sss_ip_topk(const void* q, int64_t nq, const void* corpus, int64_t n, int d,
     return sss::ip_topk(q, nq, corpus, n, d, k, dtype, id_offset, corpus_max_norm, D_out,
                         reinterpret_cast<long*>(I_out), status, unproven_count, state, state_bytes, workspace,
                         workspace_bytes, ST(stream));
+}
+int sss_split_bf16(const float* x, int64_t n, int d, uint16_t* y, void* stream) {
+    return sss::split_bf16(x, n, d, y, ST(stream));
+}
+int sss_ip_topk_split(const float* q, int64_t nq, const float* corpus, const uint16_t* corpus_split, int64_t n, int d,
+                      int k, int64_t id_offset, float corpus_max_norm, float* D_out, int64_t* I_out, int32_t* status,
+                      int32_t* unproven_count, void* state, size_t state_bytes, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    return sss::ip_topk_split(q, nq, corpus, corpus_split, n, d, k, id_offset, corpus_max_norm, D_out,
+                              reinterpret_cast<long*>(I_out), status, unproven_count, state, state_bytes, workspace,
+                              workspace_bytes, ST(stream));
 }
 size_t sss_ip_topk_exhaustive_workspace_bytes(int64_t nsel, int64_t n) {
     return sss::ip_topk_exhaustive_workspace_bytes(nsel, n);

@@ -48,22 +48,26 @@ int profile_read(double* total_ms, int* launches) {
 
 static bool fused_shape_ok(int d, int dtype) {
     const int rb = d * elem_bytes(dtype);
-    return (dtype == DT_F32 || dtype == DT_BF16) && (rb == 256 || rb == 512 || rb == 1024);
+    return (dtype == DT_F32 || dtype == DT_BF16 || dtype == DT_SPLIT) && (rb == 256 || rb == 512 || rb == 1024);
 }
 
 size_t ip_topk_state_bytes(long nq) { return nq > 0 ? state_words(nq) * 4 : 0; }
 
-size_t ip_topk_workspace_bytes(long nq, long n, int d, int k, int dtype) {
-    if (nq <= 0 || n <= 0 || k <= 0 || !fused_shape_ok(d, dtype)) return 0;
+size_t ip_topk_workspace_bytes(long nq, long n, int d, int k, int dtype) {      // dtype: the C ABI's (0 / 1)
+    if (nq <= 0 || n <= 0 || k <= 0 || (dtype != DT_F32 && dtype != DT_BF16) || !fused_shape_ok(d, dtype)) return 0;
     return make_plan(nq, n, d, k, dtype).total_bytes;
 }
 
-int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dtype, long id_offset,
-            float corpus_max_norm, float* D_out, long* I_out, int* status, int* unproven_count, void* state,
-            size_t state_bytes, void* ws, size_t ws_bytes, hipStream_t st) {
+// scan_dtype: what k_scan reads at c_scan (DT_F32 / DT_BF16: the corpus itself; DT_SPLIT: the
+// [hi | lo] bf16 image of an f32 corpus);  c_exact / exact_dtype: the rows the candidates are
+// re-scored from (and the element type of q).
+static int ip_topk_impl(const void* q, long nq, const void* c_scan, int scan_dtype, const void* c_exact, int exact_dtype,
+                        long n, int d, int k, long id_offset, float corpus_max_norm, float* D_out, long* I_out,
+                        int* status, int* unproven_count, void* state, size_t state_bytes, void* ws, size_t ws_bytes,
+                        hipStream_t st) {
     if (nq <= 0 || n <= 0 || k <= 0) { set_error("ip_topk: nq, n, k must be positive"); return SSS_EINVAL; }
-    if (!fused_shape_ok(d, dtype)) {
-        set_error("ip_topk: need dtype 0 (f32, d in {64,128,256}) or 1 (bf16, d in {128,256,512}); got dtype %d d %d", dtype, d);
+    if (!fused_shape_ok(d, scan_dtype)) {
+        set_error("ip_topk: need dtype 0 (f32, d in {64,128,256}) or 1 (bf16, d in {128,256,512}); got dtype %d d %d", exact_dtype, d);
         return SSS_EINVAL;
     }
     if (n >= (1L << 31) - 1024 || nq >= (1L << 31)) { set_error("ip_topk: n and nq must be < 2^31 per shard"); return SSS_EINVAL; }
@@ -73,12 +77,12 @@ int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dty
         return SSS_EINVAL;
     }
     if (!state || state_bytes < ip_topk_state_bytes(nq)) { set_error("ip_topk: state %zu < %zu bytes", state_bytes, ip_topk_state_bytes(nq)); return SSS_EWORKSPACE; }
-    const ScanPlan p = make_plan(nq, n, d, k, dtype);
+    const ScanPlan p = make_plan(nq, n, d, k, scan_dtype);
     if (ws_bytes < p.total_bytes) { set_error("ip_topk: workspace %zu < %zu", ws_bytes, p.total_bytes); return SSS_EWORKSPACE; }
     char* w = reinterpret_cast<char*>(ws);
 
     ScanArgs a;
-    a.Q = q; a.C = c; a.nq = (int)nq; a.n = (int)n;
+    a.Q = q; a.C = c_scan; a.nq = (int)nq; a.n = (int)n;
     a.tiles_per_split = p.tiles_per_split; a.total_tiles = p.total_tiles;
     a.S = p.S; a.G = p.G; a.J = p.J; a.cert = p.cert; a.boot = p.boot; a.cap = p.cap;
     unsigned* sw = reinterpret_cast<unsigned*>(state);
@@ -89,18 +93,35 @@ int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dty
     Prof& pr = g_prof[current_device()];
     const bool prof = pr.on && pr.n < PROF_RING;
     if (prof) (void)hipEventRecord(pr.ev[2 * pr.n], st);
-    int rc = launch_scan(dtype, d, p.tile_rows, a, st);
+    int rc = launch_scan(scan_dtype, d, p.tile_rows, a, st);
     if (prof) { (void)hipEventRecord(pr.ev[2 * pr.n + 1], st); ++pr.n; }
     if (rc) return rc;                 // nothing ran: the state is still clean
 
     SelectArgs s;
-    s.Q = q; s.C = c; s.nq = (int)nq; s.d = d; s.dtype = dtype; s.k = k; s.K2 = p.K2; s.J = p.J; s.cap = p.cap;
+    s.Q = q; s.C = c_exact; s.nq = (int)nq; s.d = d; s.dtype = exact_dtype; s.scan_dtype = scan_dtype;
+    s.k = k; s.K2 = p.K2; s.J = p.J; s.cap = p.cap;
     s.cand = a.cand; s.slots = a.slots; s.cnt = a.cnt; s.maxlast = a.maxlast;
     s.id_offset = id_offset; s.corpus_max_norm = corpus_max_norm;
     s.D_out = D_out; s.I_out = I_out; s.status = status; s.unproven_count = unproven_count;
     rc = launch_select(s, st);
     if (rc) (void)hipMemsetAsync(state, 0, ip_topk_state_bytes(nq), st);   // the scan dirtied it and nobody will clear it
     return rc;
+}
+
+int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dtype, long id_offset,
+            float corpus_max_norm, float* D_out, long* I_out, int* status, int* unproven_count, void* state,
+            size_t state_bytes, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (dtype != DT_F32 && dtype != DT_BF16) { set_error("ip_topk: dtype must be 0 (f32) or 1 (bf16), got %d", dtype); return SSS_EINVAL; }
+    return ip_topk_impl(q, nq, c, dtype, c, dtype, n, d, k, id_offset, corpus_max_norm, D_out, I_out, status,
+                        unproven_count, state, state_bytes, ws, ws_bytes, st);
+}
+
+int ip_topk_split(const float* q, long nq, const float* c, const void* c_split, long n, int d, int k, long id_offset,
+                  float corpus_max_norm, float* D_out, long* I_out, int* status, int* unproven_count, void* state,
+                  size_t state_bytes, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!c_split || (reinterpret_cast<uintptr_t>(c_split) & 15)) { set_error("ip_topk_split: split image missing or not 16-byte aligned"); return SSS_EINVAL; }
+    return ip_topk_impl(q, nq, c_split, DT_SPLIT, c, DT_F32, n, d, k, id_offset, corpus_max_norm, D_out, I_out, status,
+                        unproven_count, state, state_bytes, ws, ws_bytes, st);
 }
 
 }  // namespace sss

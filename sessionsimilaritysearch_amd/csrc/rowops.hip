@@ -106,6 +106,29 @@ __global__ __launch_bounds__(256) void k_f32_to_bf16(const float* __restrict__ x
     }
 }
 
+// f32 row [d] -> [hi(d) | lo(d)] bfloat16 (scan.h: DT_SPLIT): hi = rne(x), lo = rne(x - hi); a lo that
+// is not finite (x = +-inf, or hi rounded up to inf) is stored as 0.  8 elements per thread.
+__global__ __launch_bounds__(256) void k_split_bf16(const float* __restrict__ x, long n, int d8,
+                                                    unsigned short* __restrict__ y) {
+    const long total = n * d8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / d8;
+        const int j = (int)(i - row * d8);
+        const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        bf16x8_t hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hi[e] = (__bf16)v[e];
+            const float rem = v[e] - (float)hi[e];
+            lo[e] = (__bf16)(__builtin_isfinite(rem) ? rem : 0.f);
+        }
+        bf16x8_t* out = reinterpret_cast<bf16x8_t*>(y) + row * 2 * d8;
+        out[j] = hi;
+        out[d8 + j] = lo;
+    }
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ table,
                                                      const long* __restrict__ ids, long n, int d,
@@ -181,6 +204,15 @@ int f32_to_bf16(const float* x, long count, unsigned short* y, hipStream_t st) {
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)blocks), dim3(256), 0, st, x, count / 8, y);
     return check_launch("k_f32_to_bf16");
+}
+
+int split_bf16(const float* x, long n, int d, unsigned short* y, hipStream_t st) {
+    if (n < 0 || d <= 0 || d % 8) { set_error("split_bf16: need n >= 0, d %% 8 == 0"); return SSS_EINVAL; }
+    if (n == 0) return SSS_OK;
+    long blocks = (n * (d / 8) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)blocks), dim3(256), 0, st, x, n, d / 8, y);
+    return check_launch("k_split_bf16");
 }
 
 int gather_rows(const float* table, const long* ids, long n, int d, float* out, long ld_out, hipStream_t st) {

@@ -7,6 +7,12 @@ namespace sss {
 
 constexpr int DT_F32 = 0;       // element type codes of the C ABI (include/sss.h: dtype)
 constexpr int DT_BF16 = 1;
+// Scan-only element type (never crosses the C ABI as a corpus dtype): an f32 corpus row of d
+// elements stored as [hi(d) | lo(d)] bfloat16, hi = rne_bf16(x), lo = rne_bf16(x - hi) -- 4 bytes
+// per element like f32.  The scan scores hi*hi + hi*lo + lo*hi on the bf16 MFMA (three passes at
+// 16x the f32 MFMA rate); queries are f32 and are split by the kernel.  Candidates are re-scored
+// from the f32 rows, and the proof uses the split's own error bound (select.hip: err_bound).
+constexpr int DT_SPLIT = 2;
 
 constexpr int KP = 16;          // per-lane candidate list length (register resident)
 constexpr int WG_QUERIES = 256; // queries per scan workgroup (8 waves x 32)
@@ -50,6 +56,7 @@ struct SelectArgs {
     const void* Q;
     const void* C;
     int nq, d, dtype, k, K2, J, cap;
+    int scan_dtype;                 // what produced the candidates (DT_F32 / DT_BF16 / DT_SPLIT): picks the error bound
     const unsigned long long* cand;
     unsigned* slots;                // state arrays: read, then cleared
     unsigned* cnt;

@@ -103,7 +103,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     const int q_glob = g * WGQ + q_local;
     const int q_ld = q_glob < nq ? q_glob : nq - 1;
     f32x4 qc[NU];
-    {
+    if constexpr (DT == DT_SPLIT) {
+        // f32 queries, split here: qc[u] = hi and qc[u + NU/2] = lo of k-slice u (k = 16u + 8h .. + 7),
+        // the B operands that meet chunk 2u + h of the hi half / of the lo half of a corpus row.
+        const f32x4* qp = reinterpret_cast<const f32x4*>(Qb + (size_t)q_ld * RB) + 2 * h;
+#pragma unroll
+        for (int u = 0; u < NU / 2; ++u) {
+            const f32x4 a = qp[4 * u], b = qp[4 * u + 1];
+            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hi[e] = (__bf16)x[e];
+                const float rem = x[e] - (float)hi[e];
+                lo[e] = (__bf16)(__builtin_isfinite(rem) ? rem : 0.f);
+            }
+            qc[u] = __builtin_bit_cast(f32x4, hi);
+            qc[u + NU / 2] = __builtin_bit_cast(f32x4, lo);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(qc[u]));
+    } else {
         const f32x4* qp = reinterpret_cast<const f32x4*>(Qb + (size_t)q_ld * RB) + h;
 #pragma unroll
         for (int u = 0; u < NU; ++u) qc[u] = qp[2 * u];
@@ -265,10 +285,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, qc[u].z, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, qc[u].w, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, qc[u].w, acc1, 0, 0, 0);
-            } else {
+            } else if constexpr (DT == DT_BF16) {
                 const bf16x8 qb = __builtin_bit_cast(bf16x8, qc[u]);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), qb, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), qb, acc1, 0, 0, 0);
+            } else {
+                // split f32: chunks of the hi half meet q_hi and q_lo, chunks of the lo half meet q_hi
+                const bf16x8 A0 = __builtin_bit_cast(bf16x8, a0), A1 = __builtin_bit_cast(bf16x8, a1);
+                const bf16x8 qh = __builtin_bit_cast(bf16x8, qc[u < NU / 2 ? u : u - NU / 2]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, qh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, qh, acc1, 0, 0, 0);
+                if (u < NU / 2) {
+                    const bf16x8 ql = __builtin_bit_cast(bf16x8, qc[u + NU / 2]);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, ql, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, ql, acc1, 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             a0 = n0; a1 = n1;
@@ -468,10 +499,14 @@ int launch_scan(int dtype, int d, int tile_rows, const ScanArgs& a, hipStream_t 
         if (rb == 256) return launch_one<256, 128, DT_F32>(a, st);
         if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_F32>(a, st) : launch_one<512, 64, DT_F32>(a, st);
         if (rb == 1024) return launch_one<1024, 64, DT_F32, 4>(a, st);
-    } else {
+    } else if (dtype == DT_BF16) {
         if (rb == 256) return launch_one<256, 128, DT_BF16>(a, st);
         if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_BF16>(a, st) : launch_one<512, 64, DT_BF16>(a, st);
         if (rb == 1024) return launch_one<1024, 64, DT_BF16, 4>(a, st);
+    } else if (dtype == DT_SPLIT) {
+        if (rb == 256) return launch_one<256, 128, DT_SPLIT>(a, st);
+        if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_SPLIT>(a, st) : launch_one<512, 64, DT_SPLIT>(a, st);
+        if (rb == 1024) return launch_one<1024, 64, DT_SPLIT, 4>(a, st);
     }
     set_error("scan: unsupported row size %d bytes", rb);
     return SSS_EINVAL;

@@ -81,12 +81,22 @@ __device__ __forceinline__ float elem_to_f32(const void* row, int kk, int dtype)
     return __builtin_bit_cast(float, (unsigned)b << 16);          // bf16 -> f32 is exact
 }
 
-// B = rounding-error bound of the scan's score of any row: f32 MFMA = k-ordered fma chain,
-// d * 2^-24 * |q| |c|; the bf16 MFMA sums exact products in f32 with unspecified internal
-// order/truncation: twice that.
-__device__ __forceinline__ double err_bound(int d, int dtype, double qnorm, double cmax) {
-    const double u = dtype == DT_F32 ? 5.9604644775390625e-08 : 1.1920928955078125e-07;
-    return (double)d * u * qnorm * cmax * 1.02;
+// B = rounding-error bound of the scan's score of any row, by what the scan computed:
+//   DT_F32   k-ordered f32 fma chain:                               d * 2^-24 * |q| |c|
+//   DT_BF16  exact bf16 products summed in f32 with unspecified internal order / truncation:
+//                                                                  d * 2^-23 * |q| |c|
+//   DT_SPLIT x = xh + xl + xr with |x - xh| <= 2^-8 |x|, |xr| <= 2^-16 |x| (two roundings to 8
+//            significant bits), likewise y; the scan sums xh*yh + xh*yl + xl*yh, so per element it
+//            misses xl*yl + xr*y + (xh + xl)*yr <= 3.03 * 2^-16 |x||y|, and sum |x_k||y_k| <= |q||c|;
+//            the 3d exact products (sum of magnitudes <= 1.016 |q||c|) are accumulated in f32 like
+//            the bf16 case:                        (3.03 * 2^-16 + 3d * 2^-23 * 1.016) * |q| |c|
+// (each with 2 % headroom; |c| <= the corpus' largest row norm).
+__device__ __forceinline__ double err_bound(int d, int scan_dtype, double qnorm, double cmax) {
+    double rel;
+    if (scan_dtype == DT_F32) rel = (double)d * 5.9604644775390625e-08;
+    else if (scan_dtype == DT_BF16) rel = (double)d * 1.1920928955078125e-07;
+    else rel = 3.03 * 1.52587890625e-05 + 3.0 * (double)d * 1.1920928955078125e-07 * 1.016;
+    return rel * qnorm * cmax * 1.02;
 }
 
 // Hand the query's state words back zeroed (scan.h: the contract that replaces a per-call memset).
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     wave_sync();                                                  // every lane has read the state words
     clear_state(A, q, lane, 64);
     if (lane == 0) {
-        const double B = err_bound(A.d, A.dtype, sqrt(qn2), (double)A.corpus_max_norm);
+        const double B = err_bound(A.d, A.scan_dtype, sqrt(qn2), (double)A.corpus_max_norm);
         const int st = decide_status(sel[K2 - 1], maxlast, tau_o, A.J, nvalid, k, *s_kth, B);
         A.status[q] = st;
         if (st && A.unproven_count) atomicAdd(A.unproven_count, 1);
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
         if (tid == 0) {
             double qq = 0.0;
             for (int w = 0; w < SORT_THREADS / 64; ++w) qq += s_q2[w];
-            const double B = err_bound(A.d, A.dtype, sqrt(qq), (double)A.corpus_max_norm);
+            const double B = err_bound(A.d, A.scan_dtype, sqrt(qq), (double)A.corpus_max_norm);
             const int st = decide_status(keys[K2 - 1], maxlast, tau_o, A.J, nvalid, k, s_kth, B);
             A.status[q] = st;
             if (st && A.unproven_count) atomicAdd(A.unproven_count, 1);

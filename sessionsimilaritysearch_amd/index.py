@@ -96,15 +96,27 @@ class FlatIndex:
 
     ``dtype="bf16"`` (BASELINE config C5) stores the corpus -- and rounds every query -- to
     bfloat16 and scores on the bf16 MFMA; the contract is then defined on the ROUNDED vectors
-    (float64 dot of the stored bf16 values)."""
+    (float64 dot of the stored bf16 values).
 
-    def __init__(self, d: int, metric: str = "ip", device=None, dtype: str = "f32"):
+    ``scan`` picks how a float32 index finds its candidates (the results are the same, they are
+    re-scored from the float32 rows and proven per query either way): ``"split"`` (default) keeps
+    a second image of the corpus, each element as a bfloat16 hi/lo pair (same bytes as the f32
+    row), and scans it with three bf16 MFMA passes -- 16/3 of the f32 matrix rate;
+    ``"f32"`` scans the float32 rows on the f32 MFMA and needs no second image."""
+
+    def __init__(self, d: int, metric: str = "ip", device=None, dtype: str = "f32", scan: str | None = None):
         if metric not in ("ip", "l2"):
             raise ValueError("metric must be 'ip' or 'l2'")
         if dtype not in DTYPE_CODE:
             raise ValueError("dtype must be 'f32' or 'bf16'")
         if dtype == "bf16" and d % 8:
             raise ValueError("bf16 index needs d % 8 == 0")
+        if scan is None:
+            scan = "split" if dtype == "f32" else "native"
+        if scan not in (("split", "f32") if dtype == "f32" else ("native",)):
+            raise ValueError("scan must be 'split' or 'f32' for a float32 index")
+        self.scan = scan if (metric == "ip" and d in FUSED_DIMS[dtype]) else ("f32" if dtype == "f32" else "native")
+        self._split = None              # [cap, 2d] bf16 hi|lo image of _store (scan == "split")
         self.d = int(d)
         self.metric = metric
         self.dtype = dtype
@@ -132,9 +144,26 @@ class FlatIndex:
             store = torch.empty((cap, self.d), dtype=self._tdtype, device=self.device)
             store[:n_old] = self._xb
             self._store = store
+            if self.scan == "split":
+                split = torch.empty((cap, 2 * self.d), dtype=torch.bfloat16, device=self.device)
+                if n_old:
+                    split[:n_old] = self._split[:n_old]
+                self._split = split
         self._store[n_old:n_old + x.shape[0]] = x
         self._xb = self._store[:n_old + x.shape[0]]
+        if self.scan == "split":
+            self._split_rows(n_old, x.shape[0])
         self._norm_max(x)
+
+    def _split_rows(self, lo: int, count: int):
+        """(Re)build rows [lo, lo + count) of the hi|lo bf16 image from the float32 rows."""
+        if self._split is None or self._split.shape[0] < lo + count:
+            self._split = torch.empty((self._store.shape[0], 2 * self.d), dtype=torch.bfloat16, device=self.device)
+            lo, count = 0, self.ntotal
+        if count:
+            rc = _lib.lib().sss_split_bf16(self._xb[lo:].data_ptr(), count, self.d, self._split[lo:].data_ptr(),
+                                           _lib.stream_ptr(self.device))
+            _lib.check(rc, "sss_split_bf16")
 
     def _rows(self, x, what):
         """Input rows as a contiguous device tensor of the index's element type."""
@@ -165,6 +194,9 @@ class FlatIndex:
         self.id_offset = int(id_offset)
         self._cmax_t.zero_()
         self._norm_max(xb)
+        if self.scan == "split":
+            self._split = None
+            self._split_rows(0, xb.shape[0])
         return self
 
     def corpus_max_norm(self) -> float:
@@ -200,11 +232,15 @@ class FlatIndex:
         sbytes = L.sss_ip_topk_state_bytes(nq)
         if self._state is None or self._state.numel() < sbytes:
             self._state = torch.zeros(sbytes, dtype=torch.uint8, device=self.device)
-        rc = L.sss_ip_topk(q.data_ptr(), nq, self._xb.data_ptr(), n, self.d, k, DTYPE_CODE[self.dtype], self.id_offset,
-                           self.corpus_max_norm(), D.data_ptr(), I.data_ptr(), status.data_ptr(),
-                           0 if unproven_count is None else unproven_count.data_ptr(),
-                           self._state.data_ptr(), self._state.numel(),
-                           ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
+        tail = (self.corpus_max_norm(), D.data_ptr(), I.data_ptr(), status.data_ptr(),
+                0 if unproven_count is None else unproven_count.data_ptr(),
+                self._state.data_ptr(), self._state.numel(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
+        if self.scan == "split":
+            rc = L.sss_ip_topk_split(q.data_ptr(), nq, self._xb.data_ptr(), self._split.data_ptr(), n, self.d, k,
+                                     self.id_offset, *tail)
+        else:
+            rc = L.sss_ip_topk(q.data_ptr(), nq, self._xb.data_ptr(), n, self.d, k, DTYPE_CODE[self.dtype],
+                               self.id_offset, *tail)
         if rc != 0:
             self._state = None          # re-made (zeroed) on the next call
         _lib.check(rc, "sss_ip_topk")

@@ -17,11 +17,18 @@ def _unit(rng, n, d):
     return sr.normalize(x).astype(np.float32)
 
 
-def _index(c, cuda, metric="ip"):
+def _index(c, cuda, metric="ip", scan=None):
     from sessionsimilaritysearch_amd.index import FlatIndex
-    idx = FlatIndex(c.shape[1], metric, cuda)
+    idx = FlatIndex(c.shape[1], metric, cuda, scan=scan)
     idx.add(c)
     return idx
+
+
+@pytest.fixture(params=["split", "f32"])
+def scan(request):
+    """Both candidate scans of a float32 index: bf16 hi/lo split (3 bf16 MFMA passes, the default)
+    and the f32 MFMA.  Results must be identical (and equal to the oracle) either way."""
+    return request.param
 
 
 @pytest.mark.parametrize("nq,n,d,k", [
@@ -34,10 +41,10 @@ def _index(c, cuda, metric="ip"):
     (17, 100, 128, 16),        # k == list length
     (5, 64, 128, 1),
 ])
-def test_fused_matches_oracle(cuda, nq, n, d, k):
+def test_fused_matches_oracle(cuda, nq, n, d, k, scan):
     rng = np.random.default_rng(nq * 7919 + n)
     q, c = _unit(rng, nq, d), _unit(rng, n, d)
-    idx = _index(c, cuda)
+    idx = _index(c, cuda, scan=scan)
     D, I = idx.search(q, k)
     Dr, Ir = sr.search_exact(q, c, k)
     assert np.array_equal(I, Ir)
@@ -45,17 +52,17 @@ def test_fused_matches_oracle(cuda, nq, n, d, k):
     assert np.abs(D - Dr).max() <= 1e-5
 
 
-def test_random_data_is_proven_exact_without_fallback(cuda):
+def test_random_data_is_proven_exact_without_fallback(cuda, scan):
     rng = np.random.default_rng(5)
     q, c = _unit(rng, 512, 128), _unit(rng, 100000, 128)
-    idx = _index(c, cuda)
+    idx = _index(c, cuda, scan=scan)
     D, I = idx.search(q, 10)
     assert idx.last_fallback_queries == 0
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
-def test_duplicates_tie_break_by_id(cuda):
+def test_duplicates_tie_break_by_id(cuda, scan):
     """Exact duplicates tie exactly; the contract orders them by ascending id."""
     rng = np.random.default_rng(11)
     base = _unit(rng, 50, 128)
@@ -63,30 +70,30 @@ def test_duplicates_tie_break_by_id(cuda):
     perm = rng.permutation(c.shape[0])
     c = c[perm]
     q = _unit(rng, 40, 128)
-    idx = _index(c, cuda)
+    idx = _index(c, cuda, scan=scan)
     D, I = idx.search(q, 10)
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
-def test_all_identical_rows(cuda):
+def test_all_identical_rows(cuda, scan):
     c = np.tile(_unit(np.random.default_rng(1), 1, 128), (3000, 1))
     q = _unit(np.random.default_rng(2), 9, 128)
-    idx = _index(c, cuda)
+    idx = _index(c, cuda, scan=scan)
     D, I = idx.search(q, 10)
     assert np.array_equal(I, np.tile(np.arange(10), (9, 1)))
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(D, Dr)
 
 
-def test_sorted_adversarial_corpus(cuda):
+def test_sorted_adversarial_corpus(cuda, scan):
     """Rows ordered by ascending score for query 0: every row beats the running threshold."""
     rng = np.random.default_rng(3)
     q = _unit(rng, 4, 128)
     c = _unit(rng, 20000, 128)
     order = np.argsort(c @ q[0])
     c = np.ascontiguousarray(c[order])
-    idx = _index(c, cuda)
+    idx = _index(c, cuda, scan=scan)
     D, I = idx.search(q, 10)
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
@@ -203,48 +210,48 @@ def _search_with_status(idx, q):
 
 
 @pytest.mark.parametrize("nq,n", [(1024, 262144), (512, 300001), (200, 524288 + 77), (1024, 131072 + 5)])
-def test_large_corpus_matches_oracle_bit_exact(cuda, nq, n):
+def test_large_corpus_matches_oracle_bit_exact(cuda, nq, n, scan):
     rng = np.random.default_rng(nq + n)
     q, c = _unit(rng, nq, 128), _unit(rng, n, 128)
-    idx = _index(c, cuda)
+    idx = _index(c, cuda, scan=scan)
     D, I = _search_with_status(idx, q)
     assert idx.last_fallback_queries == 0              # random data: every query proven exact on the fused path
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
-def test_large_sorted_adversarial_corpus(cuda):
+def test_large_sorted_adversarial_corpus(cuda, scan):
     """300k rows in ascending score order for query 0 (every row beats every running threshold),
     plus ordinary queries in the same batch."""
     rng = np.random.default_rng(31)
     q = _unit(rng, 64, 128)
     c = _unit(rng, 300000, 128)
     c = np.ascontiguousarray(c[np.argsort(c @ q[0])])
-    idx = _index(c, cuda)
+    idx = _index(c, cuda, scan=scan)
     D, I = _search_with_status(idx, q)
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
     assert idx.last_fallback_queries <= 8               # at most the adversarial query (and unlucky near-ties)
 
 
-def test_large_mass_duplicates(cuda):
+def test_large_mass_duplicates(cuda, scan):
     """3000 distinct rows x 100 copies each (300k rows): the top-10 of every query is one row's
     copies, ordered by ascending id; the fused path cannot prove it and must fall back."""
     rng = np.random.default_rng(32)
     base = _unit(rng, 3000, 128)
     c = np.ascontiguousarray(np.repeat(base, 100, axis=0)[rng.permutation(300000)])
     q = _unit(rng, 24, 128)
-    idx = _index(c, cuda)
+    idx = _index(c, cuda, scan=scan)
     D, I = _search_with_status(idx, q)
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
     assert idx.last_fallback_queries == 24
 
 
-def test_large_all_identical_rows(cuda):
+def test_large_all_identical_rows(cuda, scan):
     c = np.tile(_unit(np.random.default_rng(33), 1, 128), (280000, 1))
     q = _unit(np.random.default_rng(34), 5, 128)
-    idx = _index(c, cuda)
+    idx = _index(c, cuda, scan=scan)
     D, I = _search_with_status(idx, q)
     assert np.array_equal(I, np.tile(np.arange(10), (5, 1)))
     Dr, _ = sr.search_exact(q, c[:16], 10)
@@ -265,9 +272,13 @@ def test_config_c4_10m_rows(cuda):
         c[lo:lo + 1_000_000] = torch.randn((1_000_000, d), device=cuda, generator=g)
     normalize_(c)
     q = torch.randn((nq, d), device=cuda, generator=g); normalize_(q)
-    idx = FlatIndex(d, "ip", cuda).adopt(c)
+    idx = FlatIndex(d, "ip", cuda, scan="f32").adopt(c)
     D, I, status = idx.search_fused(q, k)
     assert int(status.sum().item()) == 0
+    idx = FlatIndex(d, "ip", cuda, scan="split").adopt(c)      # the default scan: same results, also all proven
+    D2, I2, status2 = idx.search_fused(q, k)
+    assert int(status2.sum().item()) == 0
+    assert torch.equal(I2, I) and torch.equal(D2, D)
     Dn, In = D.cpu().numpy(), I.cpu().numpy()
     assert (np.diff(Dn, axis=1) <= 0).all() and (In >= 0).all() and (In < n).all()
     assert all(len(set(r.tolist())) == k for r in In)
@@ -287,6 +298,47 @@ def test_config_c4_10m_rows(cuda):
     # oracle on 16 queries (1.6e8 pairs x 128)
     Dr, Ir = sr.search_exact(q[:16].cpu().numpy(), c.cpu().numpy(), k)
     assert np.array_equal(In[:16], Ir) and np.array_equal(Dn[:16], Dr)
+
+
+def test_split_image_is_two_roundings_to_bf16(cuda):
+    """sss_split_bf16: hi = rne_bf16(x), lo = rne_bf16(x - hi); |x - hi - lo| <= 2^-16 |x|."""
+    from sessionsimilaritysearch_amd import _lib
+    rng = np.random.default_rng(70)
+    x = (rng.standard_normal((513, 64)) * np.exp(rng.uniform(-20, 20, (513, 64)))).astype(np.float32)
+    x[0, :4] = [0.0, -0.0, np.inf, -np.inf]
+    tx = torch.from_numpy(x).to(cuda)
+    y = torch.empty((513, 128), dtype=torch.bfloat16, device=cuda)
+    _lib.check(_lib.lib().sss_split_bf16(tx.data_ptr(), 513, 64, y.data_ptr(), _lib.stream_ptr(cuda)), "split")
+    hi, lo = y[:, :64].float().cpu().numpy(), y[:, 64:].float().cpu().numpy()
+    t = torch.from_numpy(x)
+    hi_ref = t.to(torch.bfloat16).float()
+    with np.errstate(invalid="ignore"):
+        rem = t - hi_ref
+    rem = torch.where(torch.isfinite(rem), rem, torch.zeros_like(rem))
+    lo_ref = rem.to(torch.bfloat16).float()
+    assert np.array_equal(hi, hi_ref.numpy()) and np.array_equal(lo, lo_ref.numpy())
+    fin = np.isfinite(x)
+    err = np.abs(x.astype(np.float64) - hi.astype(np.float64) - lo.astype(np.float64))[fin]
+    assert (err <= 2.0 ** -16 * np.abs(x[fin]).astype(np.float64) + 1e-40).all()
+
+
+def test_split_scan_near_ties_inside_its_error_bound(cuda):
+    """Clusters of rows whose scores differ by ~1e-6 -- far below what the three-pass bf16 scan
+    resolves (its bound is ~1e-4 |q||c| at d = 128), but distinct in float32.  The split scan may
+    rank them arbitrarily; the proof must notice and the answer must still be the oracle's."""
+    rng = np.random.default_rng(71)
+    base = _unit(rng, 1500, 128)
+    c = np.repeat(base, 40, axis=0) + (rng.standard_normal((60000, 128)) * 2e-6).astype(np.float32)
+    c = np.ascontiguousarray(c[rng.permutation(60000)]).astype(np.float32)
+    q = _unit(rng, 96, 128)
+    idx = _index(c, cuda, scan="split")
+    D, I = idx.search(q, 10)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    assert idx.last_fallback_queries > 0
+    # the f32 scan resolves these scores: same answer
+    D2, I2 = _index(c, cuda, scan="f32").search(q, 10)
+    assert np.array_equal(I2, Ir) and np.array_equal(D2, Dr)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -345,11 +397,11 @@ def test_bf16_duplicates_and_exhaustive_path(cuda):
     assert np.array_equal(I2, Ir2) and np.array_equal(D2, Dr2)
 
 
-def test_large_k_500_matches_oracle(cuda):
+def test_large_k_500_matches_oracle(cuda, scan):
     """sample_size = 500 neighbours (get_prediction_by_knn, test_amazon_filterd.py:61) on the fused path."""
     rng = np.random.default_rng(43)
     q, c = _unit(rng, 1024, 128), _unit(rng, 200000, 128)
-    idx = _index(c, cuda)
+    idx = _index(c, cuda, scan=scan)
     D, I = idx.search(q, 500)
     Dr, Ir = sr.search_exact(q, c, 500)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
