@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="index element type (bf16 + --d 256 --nq 4096 --corpus-source random = config C5)")
+    ap.add_argument("--scan", choices=["split", "f32"], default="split",
+                    help="candidate scan of a float32 index: 'split' = bf16 hi/lo image, three bf16 MFMA passes "
+                         "(default); 'f32' = the f32 MFMA on the float32 rows.  Results are identical.")
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--workload", choices=["search", "c3"], default="search",
                     help="c3: 4 prefix sub-sessions per session indexed, top-500 neighbours -> item vote -> top-10 items (1 GPU)")
@@ -167,7 +170,8 @@ def main():
     log(rank, f"corpus shard rows [{lo},{hi}) built in {time.time() - t0:.1f}s")
     if args.dtype == "bf16":
         xb = to_bf16(xb)
-    index = FlatIndex(d, "ip", device, dtype=args.dtype).adopt(xb, id_offset=lo)
+    index = FlatIndex(d, "ip", device, dtype=args.dtype,
+                      scan=args.scan if args.dtype == "f32" else None).adopt(xb, id_offset=lo)
     index.corpus_max_norm()
     engine = HipEngine(index)
     sharded = ShardedFlatIndex(engine, device)
@@ -310,17 +314,27 @@ def main():
     if os.path.exists(tpath):       # per-launch HBM bytes measured by the committed rocprofv3 --pmc passes
         with open(tpath) as f:
             tj = json.load(f)
-        key = f"{args.dtype}:{d}:{nq}:{hi - lo}"
+        key = f"{args.dtype if index.scan != 'split' else 'split'}:{d}:{nq}:{hi - lo}"
         if key in tj:
             traffic_detail = tj[key]
             traffic = traffic_detail["total_bytes"]
-    peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
+    # Roofline of the dominant kernel.  `achieved` is algorithmic: 2*d FLOP per (query, corpus row) pair
+    # (SURVEY.md section 8(d)).  The split scan spends three bf16 MFMA passes per pair-element, so the
+    # ceiling of ITS algorithmic rate is the dense bf16 peak / 3; pipe_* are the executed MFMA FLOP.
+    split = index.scan == "split"
+    passes = 3 if split else 1
+    if split:
+        peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
+    else:
+        peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
+    scan_name = "split" if split else args.dtype
+    dtype_name = "bf16x3" if split else args.dtype
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         line = {
             "metric": "session queries/sec", "value": round(nq * args.steps / elapsed, 1), "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype_name,
             "data": "synthetic",
             "config": {"workload": (f"{n_sessions}-session corpus x 4 prefix sub-sessions = {n_total} vectors d={d}, GNN embed + "
                                     f"cosine top-{k} neighbours + neighbour item vote -> top-{k_items} items, query batch {nq}"
@@ -337,9 +351,20 @@ def main():
                          **({"item_vote": round(vote_ms, 4)} if c3 else {})},
             **({"c3": {"sessions": n_sessions, "index_rows": n_total, "sample_size": k, "items_returned": k_items,
                        "items_bit_exact": items_exact, "queries_checked": nrq}} if c3 else {}),
-            "roofline": {"bound": "mfma", "kernel": f"k_scan<{d * (4 if args.dtype == 'f32' else 2)},*,{args.dtype}>",
+            "arithmetic": ("candidate scan: f32 rows as bf16 hi|lo pairs, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 "
+                           "(f32 accumulate); candidates re-scored in float64 from the float32 rows; per-query proof, "
+                           "exhaustive exact fallback" if split else
+                           "candidate scan on the %s MFMA; candidates re-scored in float64; per-query proof, exhaustive "
+                           "exact fallback" % args.dtype),
+            "roofline": {"bound": "mfma", "kernel": f"k_scan<{d * (2 if args.dtype == 'bf16' else 4)},*,{scan_name}>",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "B per launch (HBM, rocprofv3 PMC)",
+                         "frac": round(achieved / peak, 4),
+                         "peak_note": ("dense bf16 MFMA peak 2500 / 3 passes" if split else
+                                       "dense %s MFMA peak" % args.dtype) + " (MI355X_MICROARCH.md)",
+                         "mfma_passes": passes, "pipe_achieved": round(achieved * passes, 2),
+                         "pipe_peak": BF16_MFMA_PEAK_TFLOPS if (split or args.dtype == "bf16") else FP32_MFMA_PEAK_TFLOPS,
+                         "vs_f32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if args.dtype == "f32" else None,
+                         "traffic": traffic, "traffic_unit": "B per launch (HBM, rocprofv3 PMC)",
                          "traffic_detail": traffic_detail,
                          "kernel_ms": round(kern_ms, 4), "launches": launches.value,
                          "flop_per_launch": flop_per_launch},

@@ -53,6 +53,12 @@ __device__ __forceinline__ void list_insert(float (&ls)[N], int (&li)[N], float 
     }
 }
 
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // Two 16-byte agent-scope (sc1: not served from this CU's L1) loads + their wait, as ONE asm
 // statement so the destinations are never touched before the data has landed.
 __device__ __forceinline__ unsigned min8_sc1(const unsigned* p) {
@@ -318,18 +324,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         q3 = fmaxf(fmaxf(a[12], a[13]), fmaxf(a[14], a[15]));
         return fmaxf(fmaxf(q0, q1), fmaxf(q2, q3));
     };
-    // Top-k epilogue of one 32x32 accumulator: a[j] is (corpus row base + (j&3) + 8*(j>>2), query r).
-    // Hot path: quarter maxima (rows 8g..8g+3 of this lane's 16) + one compare.  When some lane's
-    // maximum beats its threshold, only the quarters that hold a passing score are walked.
-    auto epilogue_block = [&](const f32x16& a, int base) {
+    // Rare path of the top-k epilogue of one 32x32 accumulator: a[j] is (corpus row base + (j&3) +
+    // 8*(j>>2), query r).  Only the quarters (rows 8g..8g+3 of this lane's 16) that hold a passing
+    // score are walked.  A passing score parks in the lane's one pending slot; the 80-instruction
+    // sorted insert runs only when some lane needs its slot again (then every lane's pending entry
+    // goes in with that same pass).  thr may therefore lag behind -- it only admits extra
+    // candidates, never drops one.
+    auto insert_block = [&](const f32x16& a, int base) {
         float q0, q1, q2, q3;
         const float m = block_max(a, q0, q1, q2, q3);
-        rmax = fmaxf(rmax, m);
         if (__builtin_amdgcn_ballot_w64(m > thr) == 0) return;
-        // A passing score parks in the lane's one pending slot; the 80-instruction sorted insert
-        // runs only when some lane needs its slot again (then every lane's pending entry goes in
-        // with that same pass).  thr may therefore lag behind -- it only admits extra
-        // candidates, never drops one.
         auto walk = [&](float qm, int j0) {
             if (__builtin_amdgcn_ballot_w64(qm > thr) == 0) return;
 #pragma unroll
@@ -355,47 +359,31 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int i = 0; i < niter; ++i) {
-        const int buf = i & 1;
+    // The scan advances in 64-row steps, t = tile iteration * H + sub-step.  The loop is split in two
+    // so that the HOT loop (MFMAs, one max tree and one compare per step) never writes the list
+    // state: a step whose maximum beats some lane's threshold leaves the hot loop, runs the rare
+    // insert path on the still-live accumulators and re-enters.  (Written as one loop with the rare
+    // path inside, the register allocator cannot keep the 35 state registers in place and pays
+    // ~70 v_mov per step on the hot path.)
+    const int T = niter * H;
+    long row0_of_step = 0;                      // first corpus row of the current step
+    auto tile_top = [&](int i) {                // threshold refresh at the start of tile iteration i > 0
+        if (!use_tau || i == 0) return;
+        if (J == 16) {
+            tau_fetch();                        // lands under this tile's MFMAs
+        } else {
+            // J > 16 (k > 116): synchronous loads, rarely, staggered between the two waves of a
+            // SIMD (waves 4-7 one tile later) so the partner keeps the matrix pipe busy meanwhile.
+            const int ii = i - (wave >= 4 ? 1 : 0);        // (NW == 4: no SIMD partner, nothing to stagger)
+            if (ii >= 2 && (ii <= 8 || (ii & (ii - 1)) == 0 || (ii & 15) == 0)) set_tau(tau_ord());
+        }
+        publish();                              // completes under this tile's MFMAs
+    };
+    auto tile_end = [&](int i) {
         const bool pre = boot && i == 0;
-        const bool async_tau = use_tau && J == 16 && i > 0;
-        if (use_tau && i > 0) {
-            if (async_tau) {
-                tau_fetch();                                // lands under this iteration's MFMAs
-            } else {
-                // J > 16 (k > 116): synchronous loads, rarely, staggered between the two waves of a
-                // SIMD (waves 4-7 one tile later) so the partner keeps the matrix pipe busy meanwhile.
-                const int ii = i - (wave >= 4 ? 1 : 0);        // (NW == 4: no SIMD partner, nothing to stagger)
-                if (ii >= 2 && (ii <= 8 || (ii & (ii - 1)) == 0 || (ii & 15) == 0)) set_tau(tau_ord());
-            }
-            publish();      // completes under this tile's MFMAs
-        }
-        const int t_cur = tile_of(i);
-        for (int sub = 0; sub < H; ++sub) {
-            const int next_tile = (sub == 0 && i + 1 < niter) ? tile_of(i + 1) : -1;
-            mfma_sub(buf, sub, next_tile);
-            // acc[j] is (corpus row base + (j&3) + 8*(j>>2) + 4h, query r)
-            const long sub_row0 = (long)t_cur * TR + sub * 64;
-            if (sub_row0 + 64 > n) {                        // wave-uniform, last tile only
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int rr = (int)sub_row0 + 4 * h + (j & 3) + 8 * (j >> 2);
-                    if (rr >= n) acc0[j] = -INFINITY;
-                    if (rr + 32 >= n) acc1[j] = -INFINITY;
-                }
-            }
-            if (pre) {                                      // bootstrap: lane maximum only
-                float q0, q1, q2, q3;
-                rmax = fmaxf(rmax, block_max(acc0, q0, q1, q2, q3));
-                rmax = fmaxf(rmax, block_max(acc1, q0, q1, q2, q3));
-            } else {
-                epilogue_block(acc0, (int)sub_row0 + 4 * h);
-                epilogue_block(acc1, (int)sub_row0 + 32 + 4 * h);
-            }
-        }
         if (pre) publish();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile landed
-        if (async_tau) set_tau(tau_read());                // ... and so did its slots (own region: no barrier needed)
+        if (use_tau && J == 16 && i > 0) set_tau(tau_read());   // ... and so did its slots (own region: no barrier needed)
         __syncthreads();                                   // ... everyone's did, and this buffer is free
         if (pre) {
             // Wait (bounded) until every class of this wave's queries has published its bootstrap
@@ -410,6 +398,46 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             }
             set_tau(m);
         }
+    };
+    // MFMAs of step t into acc0 / acc1 (acc[j] is (corpus row row0 + (j&3) + 8*(j>>2) + 4h, query r),
+    // acc1 32 rows further); returns the lane's maximum over both.
+    auto score_step = [&](int t) -> float {
+        const int i = t / H, sub = t % H;
+        if (sub == 0) tile_top(i);
+        const int next_tile = (sub == 0 && i + 1 < niter) ? tile_of(i + 1) : -1;
+        mfma_sub(i & 1, sub, next_tile);
+        row0_of_step = (long)tile_of(i) * TR + sub * 64;
+        if (row0_of_step + 64 > n) {                        // wave-uniform, last tile only
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int rr = (int)row0_of_step + 4 * h + (j & 3) + 8 * (j >> 2);
+                if (rr >= n) acc0[j] = -INFINITY;
+                if (rr + 32 >= n) acc1[j] = -INFINITY;
+            }
+        }
+        // 16 v_max3 (as asm: fmaxf() adds a canonicalising v_max x, x per MFMA result it touches)
+        float m0 = vmax3(acc0[0], acc0[1], acc0[2]), m1 = vmax3(acc1[0], acc1[1], acc1[2]);
+#pragma unroll
+        for (int j = 3; j < 15; j += 2) { m0 = vmax3(m0, acc0[j], acc0[j + 1]); m1 = vmax3(m1, acc1[j], acc1[j + 1]); }
+        const float m = vmax3(m0, m1, acc0[15]);
+        const float mm = vmax3(m, acc1[15], rmax);
+        rmax = mm;
+        return vmax3(m, acc1[15], acc1[15]);
+    };
+    const int t_live = boot ? H : 0;            // steps of the bootstrap tile: lane maximum only
+    int t = 0;
+    while (t < T) {
+        bool rare = false;
+        for (; t < T; ++t) {                    // ---- hot loop
+            const float m = score_step(t);
+            if (t >= t_live && __builtin_amdgcn_ballot_w64(m > thr) != 0) { rare = true; break; }
+            if (t % H == H - 1) tile_end(t / H);
+        }
+        if (!rare) break;
+        insert_block(acc0, (int)row0_of_step + 4 * h);
+        insert_block(acc1, (int)row0_of_step + 32 + 4 * h);
+        if (t % H == H - 1) tile_end(t / H);
+        ++t;
     }
 
     list_insert<KP>(ls, li, pend_s, pend_i);   // no-op for lanes with an empty slot (-inf)
