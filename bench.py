@@ -119,9 +119,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="index element type (bf16 + --d 256 --nq 4096 --corpus-source random = config C5)")
-    ap.add_argument("--scan", choices=["split", "f32"], default="split",
-                    help="candidate scan of a float32 index: 'split' = bf16 hi/lo image, three bf16 MFMA passes "
-                         "(default); 'f32' = the f32 MFMA on the float32 rows.  Results are identical.")
+    ap.add_argument("--scan", choices=["auto", "f16", "split", "f32"], default="auto",
+                    help="candidate scan of a float32 index: 'f16' = scaled float16 image, one f16 MFMA pass; "
+                         "'split' = bf16 hi/lo image, three bf16 MFMA passes; 'f32' = the f32 MFMA on the float32 "
+                         "rows; 'auto' (default) = f16 for k <= 16, split beyond.  Results are identical.")
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--workload", choices=["search", "c3"], default="search",
                     help="c3: 4 prefix sub-sessions per session indexed, top-500 neighbours -> item vote -> top-10 items (1 GPU)")
@@ -172,7 +173,7 @@ def main():
         xb = to_bf16(xb)
     index = FlatIndex(d, "ip", device, dtype=args.dtype,
                       scan=args.scan if args.dtype == "f32" else None).adopt(xb, id_offset=lo)
-    index.corpus_max_norm()
+    index.prepare(args.k if args.workload != "c3" else args.sample_size)     # images + norms now, not in the first timed search
     engine = HipEngine(index)
     sharded = ShardedFlatIndex(engine, device)
 
@@ -309,26 +310,30 @@ def main():
                          f"float32 SGEMM/top-k (faiss-shaped) over {sample} of {n_total} corpus rows "
                          f"({t_search:.3f}s, scaled linearly to the full corpus)"}
 
+    mode = index.last_scan          # the scan the timed searches used
     traffic = traffic_detail = None
     tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if os.path.exists(tpath):       # per-launch HBM bytes measured by the committed rocprofv3 --pmc passes
         with open(tpath) as f:
             tj = json.load(f)
-        key = f"{args.dtype if index.scan != 'split' else 'split'}:{d}:{nq}:{hi - lo}"
+        key = f"{args.dtype if mode in ('f32', 'native') else mode}:{d}:{nq}:{hi - lo}"
         if key in tj:
             traffic_detail = tj[key]
             traffic = traffic_detail["total_bytes"]
     # Roofline of the dominant kernel.  `achieved` is algorithmic: 2*d FLOP per (query, corpus row) pair
     # (SURVEY.md section 8(d)).  The split scan spends three bf16 MFMA passes per pair-element, so the
     # ceiling of ITS algorithmic rate is the dense bf16 peak / 3; pipe_* are the executed MFMA FLOP.
-    split = index.scan == "split"
+    split = mode == "split"
+    f16 = mode == "f16"
     passes = 3 if split else 1
     if split:
         peak = round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
+    elif f16:
+        peak = BF16_MFMA_PEAK_TFLOPS            # the guide's dense f16 rate is the bf16 rate
     else:
         peak = FP32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_MFMA_PEAK_TFLOPS
-    scan_name = "split" if split else args.dtype
-    dtype_name = "bf16x3" if split else args.dtype
+    scan_name = mode if (split or f16) else args.dtype
+    dtype_name = "bf16x3" if split else "f16" if f16 else args.dtype
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         line = {
@@ -354,15 +359,19 @@ def main():
             "arithmetic": ("candidate scan: f32 rows as bf16 hi|lo pairs, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 "
                            "(f32 accumulate); candidates re-scored in float64 from the float32 rows; per-query proof, "
                            "exhaustive exact fallback" if split else
+                           "candidate scan: f32 rows and queries scaled by a power of two and rounded to float16, one pass of "
+                           "v_mfma_f32_32x32x16_f16 (f32 accumulate); candidates re-scored in float64 from the float32 rows; "
+                           "per-query proof from the measured rounding residuals, exhaustive exact fallback" if f16 else
                            "candidate scan on the %s MFMA; candidates re-scored in float64; per-query proof, exhaustive "
                            "exact fallback" % args.dtype),
-            "roofline": {"bound": "mfma", "kernel": f"k_scan<{d * (2 if args.dtype == 'bf16' else 4)},*,{scan_name}>",
+            "roofline": {"bound": "mfma", "kernel": f"k_scan<{d * (2 if (args.dtype == 'bf16' or f16) else 4)},*,{scan_name}>",
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4),
                          "peak_note": ("dense bf16 MFMA peak 2500 / 3 passes" if split else
+                                       "dense f16 MFMA peak (= the bf16 rate)" if f16 else
                                        "dense %s MFMA peak" % args.dtype) + " (MI355X_MICROARCH.md)",
                          "mfma_passes": passes, "pipe_achieved": round(achieved * passes, 2),
-                         "pipe_peak": BF16_MFMA_PEAK_TFLOPS if (split or args.dtype == "bf16") else FP32_MFMA_PEAK_TFLOPS,
+                         "pipe_peak": BF16_MFMA_PEAK_TFLOPS if (split or f16 or args.dtype == "bf16") else FP32_MFMA_PEAK_TFLOPS,
                          "vs_f32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4) if args.dtype == "f32" else None,
                          "traffic": traffic, "traffic_unit": "B per launch (HBM, rocprofv3 PMC)",
                          "traffic_detail": traffic_detail,

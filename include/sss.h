@@ -83,6 +83,34 @@ int sss_ip_topk_split(const float* q, int64_t nq, const float* corpus, const uin
                       int64_t* I_out, int32_t* status, int32_t* unproven_count, void* state,
                       size_t state_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same search with the candidates found by ONE float16 MFMA pass over a scaled float16 image of
+ * the float32 corpus (half the bytes, a third of the split scan's matrix work; the default of the
+ * Python FlatIndex for d in {128,256,512}):
+ *   corpus_f16 [n, d] float16 = round_to_nearest_even(corpus * 2^corpus_shift), made by
+ *   sss_scale_f16; corpus_shift = sss_f16_shift(largest |element| of the corpus) (sss_abs_max), which
+ *   puts that element in [2^12, 2^13) -- an exact scaling far from both ends of the f16 range.  A
+ *   shift stays valid while every element times 2^shift is below 65504 (the index re-scales when
+ *   an added row exceeds 2^15).
+ * The kernel scales and rounds each float32 query the same way (its own shift), so scan scores
+ * are the true scores times a per-query power of two: thresholds and candidate choice are
+ * unaffected, and the proof divides it out.  Error bound of a scan score:
+ * Rc |q| + (|c| + Rc) Rq + (2^-25 sqrt(d) + d 2^-23) |q| |c|, with Rq the query's own rounding
+ * residual norm (measured by the kernel) and Rc = corpus_resid_norm = the largest row norm of
+ * (corpus_f16 * 2^-corpus_shift - corpus), measured by sss_f16_resid_max when the image is built
+ * (any upper bound is valid; the worst case is 2^-11 * corpus_max_norm).  Coarser than the other
+ * scans (~4e-4 |q||c| at d = 128), so more near-ties are left unproven (status != 0) and go to
+ * sss_ip_topk_exhaustive; results for status 0 are identical.
+ * q float32 [nq, d]; workspace: sss_ip_topk_f16_workspace_bytes(nq, n, d, k); state as above. */
+int sss_abs_max(const float* x, int64_t count, float* out, void* stream);   /* max |x_i| -> *out (device, caller zeroes); count % 4 == 0 */
+int sss_f16_shift(float amax);                                              /* host helper: the shift for a largest magnitude */
+int sss_scale_f16(const float* x, int64_t count, int shift, uint16_t* y, void* stream);   /* count % 8 == 0 */
+int sss_f16_resid_max(const float* x, const uint16_t* y, int64_t n, int d, int shift, float* out, void* stream);   /* *out: device float, caller zeroes */
+size_t sss_ip_topk_f16_workspace_bytes(int64_t nq, int64_t n, int d, int k);
+int sss_ip_topk_f16(const float* q, int64_t nq, const float* corpus, const uint16_t* corpus_f16,
+                    int corpus_shift, float corpus_resid_norm, int64_t n, int d, int k, int64_t id_offset, float corpus_max_norm,
+                    float* D_out, int64_t* I_out, int32_t* status, int32_t* unproven_count, void* state,
+                    size_t state_bytes, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Exhaustive exact search for a (small) set of queries: qsel [nsel] int32 are the query rows of
  * q to process; results are written to rows qsel[i] of D_out / I_out.  Any n, any d % 4 == 0
  * (dtype 0) or d % 8 == 0 (dtype 1), k <= 1024.  metric: 0 = inner product, 1 = squared L2

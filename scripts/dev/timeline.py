@@ -1,0 +1,44 @@
+"""Dev helper (not product): per-workgroup timeline of k_scan from a -DSSS_TIMELINE build of libsss
+(scripts/dev/libsss_tl.so, built by hand: see DESIGN.md "in-kernel stamps").  Usage: timeline.py nq n d k"""
+import sys, os, ctypes, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from sessionsimilaritysearch_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsss_tl.so")
+import torch
+from sessionsimilaritysearch_amd.index import FlatIndex, normalize_
+
+nq, n, d, k = (int(v) for v in sys.argv[1:5])
+scan = sys.argv[5] if len(sys.argv) > 5 else "split"
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev); g.manual_seed(1)
+c = torch.randn((n, d), device=dev, generator=g); normalize_(c)
+q = torch.randn((nq, d), device=dev, generator=g); normalize_(q)
+idx = FlatIndex(d, "ip", dev, scan=scan).adopt(c)
+idx.corpus_max_norm()
+out = idx.search_fused(q, k)
+for _ in range(20):
+    idx.search_fused(q, k, out)
+torch.cuda.synchronize()
+L = _lib.lib()
+nwg = 256
+buf = (ctypes.c_ulonglong * (nwg * 8))()
+fn = L.sss_debug_timeline
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+rc = fn(buf, nwg * 8)
+a = np.array(buf, dtype=np.uint64).reshape(nwg, 8).astype(np.int64)
+rt0, rt1 = a[:, 0], a[:, 7]
+t = a[:, 1:6]
+start_skew_us = (rt0 - rt0.min()) / 100.0
+end_us = (rt1 - rt0.min()) / 100.0
+dur_us = (rt1 - rt0) / 100.0
+cyc = t[:, 4] - t[:, 0]
+ghz = cyc / (dur_us * 1e3)
+print(json.dumps(dict(rc=rc, nq=nq, n=n, d=d, k=k, scan=scan,
+    kernel_us=float(end_us.max()), start_skew_us_max=float(start_skew_us.max()),
+    wg_dur_us=dict(min=float(dur_us.min()), med=float(np.median(dur_us)), max=float(dur_us.max())),
+    end_us=dict(min=float(end_us.min()), med=float(np.median(end_us)), max=float(end_us.max())),
+    clock_ghz_med=float(np.median(ghz)),
+    prologue_cyc_med=float(np.median(t[:, 2] - t[:, 0])), loop_cyc_med=float(np.median(t[:, 3] - t[:, 2])),
+    loop_cyc_min=float((t[:, 3] - t[:, 2]).min()), loop_cyc_max=float((t[:, 3] - t[:, 2]).max()),
+    tail_cyc_med=float(np.median(t[:, 4] - t[:, 3])), rare_med=float(np.median(a[:, 6])), rare_max=int(a[:, 6].max()))))

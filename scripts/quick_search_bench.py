@@ -15,8 +15,8 @@ def run(nq, n, d, k, dtype="f32", iters=5):
         from sessionsimilaritysearch_amd.index import to_bf16
         c, q = to_bf16(c), to_bf16(q)
     scan = None
-    if dtype in ("split", "f32mfma"):           # float32 index, explicit candidate scan
-        scan, dtype = ("split" if dtype == "split" else "f32"), "f32"
+    if dtype in ("f16", "split", "f32mfma"):    # float32 index, explicit candidate scan
+        scan, dtype = ("f32" if dtype == "f32mfma" else dtype), "f32"
     idx = FlatIndex(d, "ip", dev, dtype=dtype, scan=scan).adopt(c)
     idx.corpus_max_norm()
     out = idx.search_fused(q, k)
@@ -29,7 +29,7 @@ def run(nq, n, d, k, dtype="f32", iters=5):
     ms = e0.elapsed_time(e1) / iters
     tf = 2.0 * nq * n * d / (ms * 1e-3) / 1e12
     bad = int(out[2].sum().item())
-    print(json.dumps(dict(nq=nq, n=n, d=d, k=k, dtype=dtype, scan=idx.scan, ms=round(ms, 4), tflops=round(tf, 2), frac=round(tf / PEAK[dtype], 4),
+    print(json.dumps(dict(nq=nq, n=n, d=d, k=k, dtype=dtype, scan=idx.last_scan, ms=round(ms, 4), tflops=round(tf, 2), frac=round(tf / PEAK[dtype], 4),
                           qps=round(nq / (ms * 1e-3)), unproven=bad)), flush=True)
 
 if __name__ == "__main__":

@@ -31,6 +31,14 @@ _SIGNATURES = {
     "sss_ip_topk_split": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_float,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                                   c_void_p]),
+    "sss_abs_max": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "sss_f16_shift": (c_int, [c_float]),
+    "sss_scale_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "sss_ip_topk_f16_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "sss_f16_resid_max": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "sss_ip_topk_f16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_float, c_int64, c_int, c_int, c_int64, c_float,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
+                                c_void_p]),
     "sss_ip_topk_exhaustive_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sss_ip_topk_exhaustive": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                        c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t,

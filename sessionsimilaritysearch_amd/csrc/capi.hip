@@ -4,6 +4,7 @@
 
 #include "../../include/sss.h"
 #include "sss_common.h"
+#include "scan.h"
 
 namespace sss {
 
@@ -33,6 +34,12 @@ int ip_topk(const void*, long, const void*, long, int, int, int, long, float, fl
 int ip_topk_split(const float*, long, const float*, const void*, long, int, int, long, float, float*, long*, int*, int*, void*,
                   size_t, void*, size_t, hipStream_t);
 int split_bf16(const float*, long, int, unsigned short*, hipStream_t);
+int ip_topk_f16(const float*, long, const float*, const void*, int, float, long, int, int, long, float, float*, long*, int*, int*,
+                void*, size_t, void*, size_t, hipStream_t);
+int f16_resid_max(const float*, const unsigned short*, long, int, int, float*, hipStream_t);
+size_t ip_topk_scan_workspace_bytes(long, long, int, int, int);
+int abs_max(const float*, long, float*, hipStream_t);
+int scale_f16(const float*, long, int, unsigned short*, hipStream_t);
 int topk_merge(const float*, long, const long*, long, int, long, int, float*, long*, hipStream_t);
 int profile_enable(int);
 int profile_read(double*, int*);
@@ -100,7 +107,7 @@ int graph_fill(const long*, const unsigned char*, const long*, const long*, long
 
 extern "C" {
 
-int sss_version(void) { return 210; }
+int sss_version(void) { return 220; }
 const char* sss_last_error(void) { return sss::g_err; }
 
 int sss_normalize_rows(float* x, int64_t n, int d, int64_t ld, float eps, int rule, void* stream) {
@@ -133,6 +140,25 @@ int sss_ip_topk_split(const float* q, int64_t nq, const float* corpus, const uin
     return sss::ip_topk_split(q, nq, corpus, corpus_split, n, d, k, id_offset, corpus_max_norm, D_out,
                               reinterpret_cast<long*>(I_out), status, unproven_count, state, state_bytes, workspace,
                               workspace_bytes, ST(stream));
+}
+int sss_abs_max(const float* x, int64_t count, float* out, void* stream) { return sss::abs_max(x, count, out, ST(stream)); }
+int sss_f16_shift(float amax) { return sss::f16_shift(amax); }
+int sss_scale_f16(const float* x, int64_t count, int shift, uint16_t* y, void* stream) {
+    return sss::scale_f16(x, count, shift, y, ST(stream));
+}
+size_t sss_ip_topk_f16_workspace_bytes(int64_t nq, int64_t n, int d, int k) {
+    return sss::ip_topk_scan_workspace_bytes(nq, n, d, k, sss::DT_F16);
+}
+int sss_f16_resid_max(const float* x, const uint16_t* y, int64_t n, int d, int shift, float* out, void* stream) {
+    return sss::f16_resid_max(x, y, n, d, shift, out, ST(stream));
+}
+int sss_ip_topk_f16(const float* q, int64_t nq, const float* corpus, const uint16_t* corpus_f16, int corpus_shift,
+                    float corpus_resid_norm, int64_t n, int d, int k, int64_t id_offset, float corpus_max_norm, float* D_out, int64_t* I_out,
+                    int32_t* status, int32_t* unproven_count, void* state, size_t state_bytes, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    return sss::ip_topk_f16(q, nq, corpus, corpus_f16, corpus_shift, corpus_resid_norm, n, d, k, id_offset, corpus_max_norm, D_out,
+                            reinterpret_cast<long*>(I_out), status, unproven_count, state, state_bytes, workspace,
+                            workspace_bytes, ST(stream));
 }
 size_t sss_ip_topk_exhaustive_workspace_bytes(int64_t nsel, int64_t n) {
     return sss::ip_topk_exhaustive_workspace_bytes(nsel, n);

@@ -48,7 +48,7 @@ int profile_read(double* total_ms, int* launches) {
 
 static bool fused_shape_ok(int d, int dtype) {
     const int rb = d * elem_bytes(dtype);
-    return (dtype == DT_F32 || dtype == DT_BF16 || dtype == DT_SPLIT) && (rb == 256 || rb == 512 || rb == 1024);
+    return (dtype == DT_F32 || dtype == DT_BF16 || dtype == DT_SPLIT || dtype == DT_F16) && (rb == 256 || rb == 512 || rb == 1024);
 }
 
 size_t ip_topk_state_bytes(long nq) { return nq > 0 ? state_words(nq) * 4 : 0; }
@@ -58,11 +58,17 @@ size_t ip_topk_workspace_bytes(long nq, long n, int d, int k, int dtype) {      
     return make_plan(nq, n, d, k, dtype).total_bytes;
 }
 
+size_t ip_topk_scan_workspace_bytes(long nq, long n, int d, int k, int scan_dtype) {   // scan.h codes (0..3)
+    if (nq <= 0 || n <= 0 || k <= 0 || !fused_shape_ok(d, scan_dtype)) return 0;
+    return make_plan(nq, n, d, k, scan_dtype).total_bytes;
+}
+
 // scan_dtype: what k_scan reads at c_scan (DT_F32 / DT_BF16: the corpus itself; DT_SPLIT: the
-// [hi | lo] bf16 image of an f32 corpus);  c_exact / exact_dtype: the rows the candidates are
-// re-scored from (and the element type of q).
-static int ip_topk_impl(const void* q, long nq, const void* c_scan, int scan_dtype, const void* c_exact, int exact_dtype,
-                        long n, int d, int k, long id_offset, float corpus_max_norm, float* D_out, long* I_out,
+// [hi | lo] bf16 image of an f32 corpus; DT_F16: its scaled f16 image, corpus * 2^corpus_shift);
+// c_exact / exact_dtype: the rows the candidates are re-scored from (and the element type of q).
+static int ip_topk_impl(const void* q, long nq, const void* c_scan, int scan_dtype, int corpus_shift, float corpus_resid,
+                        const void* c_exact,
+                        int exact_dtype, long n, int d, int k, long id_offset, float corpus_max_norm, float* D_out, long* I_out,
                         int* status, int* unproven_count, void* state, size_t state_bytes, void* ws, size_t ws_bytes,
                         hipStream_t st) {
     if (nq <= 0 || n <= 0 || k <= 0) { set_error("ip_topk: nq, n, k must be positive"); return SSS_EINVAL; }
@@ -98,7 +104,7 @@ static int ip_topk_impl(const void* q, long nq, const void* c_scan, int scan_dty
     if (rc) return rc;                 // nothing ran: the state is still clean
 
     SelectArgs s;
-    s.Q = q; s.C = c_exact; s.nq = (int)nq; s.d = d; s.dtype = exact_dtype; s.scan_dtype = scan_dtype;
+    s.Q = q; s.C = c_exact; s.nq = (int)nq; s.d = d; s.dtype = exact_dtype; s.scan_dtype = scan_dtype; s.corpus_shift = corpus_shift; s.corpus_resid = corpus_resid;
     s.k = k; s.K2 = p.K2; s.J = p.J; s.cap = p.cap;
     s.cand = a.cand; s.slots = a.slots; s.cnt = a.cnt; s.maxlast = a.maxlast;
     s.id_offset = id_offset; s.corpus_max_norm = corpus_max_norm;
@@ -112,7 +118,7 @@ int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dty
             float corpus_max_norm, float* D_out, long* I_out, int* status, int* unproven_count, void* state,
             size_t state_bytes, void* ws, size_t ws_bytes, hipStream_t st) {
     if (dtype != DT_F32 && dtype != DT_BF16) { set_error("ip_topk: dtype must be 0 (f32) or 1 (bf16), got %d", dtype); return SSS_EINVAL; }
-    return ip_topk_impl(q, nq, c, dtype, c, dtype, n, d, k, id_offset, corpus_max_norm, D_out, I_out, status,
+    return ip_topk_impl(q, nq, c, dtype, 0, 0.f, c, dtype, n, d, k, id_offset, corpus_max_norm, D_out, I_out, status,
                         unproven_count, state, state_bytes, ws, ws_bytes, st);
 }
 
@@ -120,8 +126,18 @@ int ip_topk_split(const float* q, long nq, const float* c, const void* c_split, 
                   float corpus_max_norm, float* D_out, long* I_out, int* status, int* unproven_count, void* state,
                   size_t state_bytes, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!c_split || (reinterpret_cast<uintptr_t>(c_split) & 15)) { set_error("ip_topk_split: split image missing or not 16-byte aligned"); return SSS_EINVAL; }
-    return ip_topk_impl(q, nq, c_split, DT_SPLIT, c, DT_F32, n, d, k, id_offset, corpus_max_norm, D_out, I_out, status,
+    return ip_topk_impl(q, nq, c_split, DT_SPLIT, 0, 0.f, c, DT_F32, n, d, k, id_offset, corpus_max_norm, D_out, I_out, status,
                         unproven_count, state, state_bytes, ws, ws_bytes, st);
+}
+
+int ip_topk_f16(const float* q, long nq, const float* c, const void* c_f16, int corpus_shift, float corpus_resid, long n, int d, int k,
+                long id_offset, float corpus_max_norm, float* D_out, long* I_out, int* status, int* unproven_count,
+                void* state, size_t state_bytes, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!c_f16 || (reinterpret_cast<uintptr_t>(c_f16) & 15)) { set_error("ip_topk_f16: f16 image missing or not 16-byte aligned"); return SSS_EINVAL; }
+    if (corpus_shift < -160 || corpus_shift > 160) { set_error("ip_topk_f16: corpus_shift out of range"); return SSS_EINVAL; }
+    if (!(corpus_resid >= 0.f)) { set_error("ip_topk_f16: corpus_resid_norm must be >= 0"); return SSS_EINVAL; }
+    return ip_topk_impl(q, nq, c_f16, DT_F16, corpus_shift, corpus_resid, c, DT_F32, n, d, k, id_offset, corpus_max_norm, D_out, I_out,
+                        status, unproven_count, state, state_bytes, ws, ws_bytes, st);
 }
 
 }  // namespace sss

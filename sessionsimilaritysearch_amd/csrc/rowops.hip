@@ -129,6 +129,54 @@ __global__ __launch_bounds__(256) void k_split_bf16(const float* __restrict__ x,
     }
 }
 
+// max |x_i| over `count` contiguous floats -> *out (atomic max on the bit pattern of a non-negative
+// float; caller zeroes).  NaNs are ignored (fmaxf), +-inf gives inf.  count % 4 == 0.
+__global__ __launch_bounds__(256) void k_abs_max(const float* __restrict__ x, long n4, float* __restrict__ out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+
+// f32 -> float16 of x * 2^shift (scan.h: DT_F16), round to nearest even; 8 elements per thread.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_scale_f16(const float* __restrict__ x, long n8, int shift,
+                                                   unsigned short* __restrict__ y) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+        f16x8_t o;
+        o[0] = (_Float16)ldexpf(a.x, shift); o[1] = (_Float16)ldexpf(a.y, shift);
+        o[2] = (_Float16)ldexpf(a.z, shift); o[3] = (_Float16)ldexpf(a.w, shift);
+        o[4] = (_Float16)ldexpf(b.x, shift); o[5] = (_Float16)ldexpf(b.y, shift);
+        o[6] = (_Float16)ldexpf(b.z, shift); o[7] = (_Float16)ldexpf(b.w, shift);
+        reinterpret_cast<f16x8_t*>(y)[i] = o;
+    }
+}
+
+// max over rows of || y_i * 2^-shift - x_i ||_2 (y the scaled f16 image of x) -> *out, atomically
+// maximised (caller zeroes): the corpus residual of the DT_F16 error bound.  One wave per row.
+__global__ __launch_bounds__(256) void k_f16_resid_max(const float* __restrict__ x, const _Float16* __restrict__ y,
+                                                       long n, int d, int shift, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    float m = 0.f;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (long)gridDim.x * 4) {
+        double s = 0.0;
+        for (int kk = lane; kk < d; kk += 64) {
+            const double r = (double)ldexpf((float)y[row * d + kk], -shift) - (double)x[row * d + kk];
+            s += r * r;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float f = (float)(sqrt(s) * (1.0 + 1e-6));       // rounded up
+        if (f == f) m = fmaxf(m, f);
+    }
+    if (lane == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+
 template <int LPR>
 __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ table,
                                                      const long* __restrict__ ids, long n, int d,
@@ -213,6 +261,35 @@ int split_bf16(const float* x, long n, int d, unsigned short* y, hipStream_t st)
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_split_bf16, dim3((unsigned)blocks), dim3(256), 0, st, x, n, d / 8, y);
     return check_launch("k_split_bf16");
+}
+
+int abs_max(const float* x, long count, float* out, hipStream_t st) {
+    if (count < 0 || count % 4) { set_error("abs_max: element count must be a multiple of 4"); return SSS_EINVAL; }
+    if (count == 0) return SSS_OK;
+    long blocks = (count / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_abs_max, dim3((unsigned)blocks), dim3(256), 0, st, x, count / 4, out);
+    return check_launch("k_abs_max");
+}
+
+int scale_f16(const float* x, long count, int shift, unsigned short* y, hipStream_t st) {
+    if (count < 0 || count % 8) { set_error("scale_f16: element count must be a multiple of 8"); return SSS_EINVAL; }
+    if (shift < -160 || shift > 160) { set_error("scale_f16: shift out of range"); return SSS_EINVAL; }
+    if (count == 0) return SSS_OK;
+    long blocks = (count / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_scale_f16, dim3((unsigned)blocks), dim3(256), 0, st, x, count / 8, shift, y);
+    return check_launch("k_scale_f16");
+}
+
+int f16_resid_max(const float* x, const unsigned short* y, long n, int d, int shift, float* out, hipStream_t st) {
+    if (n < 0 || d <= 0 || shift < -160 || shift > 160) { set_error("f16_resid_max: bad arguments"); return SSS_EINVAL; }
+    if (n == 0) return SSS_OK;
+    long blocks = (n + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_f16_resid_max, dim3((unsigned)blocks), dim3(256), 0, st, x, reinterpret_cast<const _Float16*>(y), n,
+                       d, shift, out);
+    return check_launch("k_f16_resid_max");
 }
 
 int gather_rows(const float* table, const long* ids, long n, int d, float* out, long ld_out, hipStream_t st) {

@@ -13,13 +13,30 @@ constexpr int DT_BF16 = 1;
 // 16x the f32 MFMA rate); queries are f32 and are split by the kernel.  Candidates are re-scored
 // from the f32 rows, and the proof uses the split's own error bound (select.hip: err_bound).
 constexpr int DT_SPLIT = 2;
+// Scan-only element type: an f32 corpus stored as float16 after an exact power-of-two scaling,
+// x * 2^shift with ONE shift for the whole corpus chosen so that the largest |element| lies in
+// [2^12, 2^13) (f16_shift below: far from both ends of the f16 range) -- 2 bytes per element.  The
+// kernel scales each f32 query by its own power of two the same way, so a scan score is the true
+// score times 2^(corpus shift + query shift): thresholds and candidate selection work in that
+// domain (per query it is a fixed positive factor), and the select kernel divides it out for the
+// proof.  One f16 MFMA pass (1/3 of DT_SPLIT's matrix work, half its bytes) with a coarser bound
+// (select.hip: err_bound ~ 2^-10 |q||c|), still proven per query and re-scored from the f32 rows.
+constexpr int DT_F16 = 3;
+
+// shift that maps a largest magnitude `amax` into [2^12, 2^13); 0 for an all-zero / non-finite row
+__host__ __device__ inline int f16_shift(float amax) {
+    if (!(amax > 0.f) || !(amax <= 3.0e38f)) return 0;
+    int e;
+    (void)frexpf(amax, &e);          // amax = m * 2^e, m in [0.5, 1)
+    return 13 - e;
+}
 
 constexpr int KP = 16;          // per-lane candidate list length (register resident)
 constexpr int WG_QUERIES = 256; // queries per scan workgroup (8 waves x 32)
 constexpr int MAX_SLOTS = 128;  // admission-threshold slots per query (J <= MAX_SLOTS)
 constexpr unsigned ORD_NEG_INF = 0x007FFFFFu;   // f2ord(-inf); slot value 0 = "never written"
 
-static inline int elem_bytes(int dtype) { return dtype == DT_BF16 ? 2 : 4; }
+static inline int elem_bytes(int dtype) { return (dtype == DT_BF16 || dtype == DT_F16) ? 2 : 4; }
 
 // STATE words (caller-owned, zero before the first call; every call leaves them zero: the select
 // kernel, their last reader, clears what the call used -- no per-call memset launch).  Because the
@@ -56,7 +73,9 @@ struct SelectArgs {
     const void* Q;
     const void* C;
     int nq, d, dtype, k, K2, J, cap;
-    int scan_dtype;                 // what produced the candidates (DT_F32 / DT_BF16 / DT_SPLIT): picks the error bound
+    int scan_dtype;                 // what produced the candidates (DT_F32 / DT_BF16 / DT_SPLIT / DT_F16): picks the error bound
+    int corpus_shift;               // DT_F16: the corpus image is corpus * 2^corpus_shift (else 0)
+    float corpus_resid;             // DT_F16: largest row norm of (image * 2^-corpus_shift - corpus)
     const unsigned long long* cand;
     unsigned* slots;                // state arrays: read, then cleared
     unsigned* cnt;

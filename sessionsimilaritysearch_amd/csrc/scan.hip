@@ -35,6 +35,7 @@ namespace sss {
 
 typedef char __attribute__((address_space(3)))* lptr_c;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Sorted (descending) insert of (x, id) into a register list; lanes whose x does not beat
@@ -74,8 +75,15 @@ __device__ __forceinline__ unsigned min8_sc1(const unsigned* p) {
 
 // NW = waves per workgroup: 8 (two per SIMD, 256 VGPRs each) or, for 1024-byte rows whose resident
 // queries alone take 128 VGPRs, 4 (one per SIMD, 512 VGPRs: no spills; NW * 32 queries per workgroup).
+#ifdef SSS_TIMELINE
+__device__ unsigned long long g_tl[1024 * 8];
+#define TL(slot) do { if (threadIdx.x == 0) g_tl[blockIdx.x * 8 + (slot)] = ((slot) == 0 || (slot) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TL(slot) do {} while (0)
+#endif
 template <int RB, int TR, int DT, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
+    TL(0); TL(1);
     constexpr int H = TR / 64;                        // 64-row sub-steps per tile
     constexpr int CH = RB / 16;                       // 16-byte chunks per row
     constexpr int NU = RB / 32;                       // k-groups per row (one b128 fragment each)
@@ -126,6 +134,31 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             }
             qc[u] = __builtin_bit_cast(f32x4, hi);
             qc[u + NU / 2] = __builtin_bit_cast(f32x4, lo);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(qc[u]));
+    } else if constexpr (DT == DT_F16) {
+        // f32 queries (4 * (RB / 2) bytes per row), scaled by the query's own power of two (scan.h:
+        // f16_shift of its largest |element|) and rounded to f16: qc[u] = k-slice u (k = 16u + 8h .. + 7).
+        const f32x4* qp = reinterpret_cast<const f32x4*>(Qb + (size_t)q_ld * (2 * RB)) + 2 * h;
+        f32x4 raw[2 * NU];
+        float amax = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { raw[2 * u] = qp[4 * u]; raw[2 * u + 1] = qp[4 * u + 1]; }
+#pragma unroll
+        for (int u = 0; u < 2 * NU; ++u)
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(raw[u].x), fabsf(raw[u].y))), fmaxf(fabsf(raw[u].z), fabsf(raw[u].w)));
+        amax = fmaxf(amax, __shfl_xor(amax, 32));            // the other half of the row
+        const int sh = f16_shift(amax);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const f32x4 a = raw[2 * u], b = raw[2 * u + 1];
+            f16x8 v;
+            v[0] = (_Float16)ldexpf(a.x, sh); v[1] = (_Float16)ldexpf(a.y, sh);
+            v[2] = (_Float16)ldexpf(a.z, sh); v[3] = (_Float16)ldexpf(a.w, sh);
+            v[4] = (_Float16)ldexpf(b.x, sh); v[5] = (_Float16)ldexpf(b.y, sh);
+            v[6] = (_Float16)ldexpf(b.z, sh); v[7] = (_Float16)ldexpf(b.w, sh);
+            qc[u] = __builtin_bit_cast(f32x4, v);
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(qc[u]));
@@ -295,6 +328,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
                 const bf16x8 qb = __builtin_bit_cast(bf16x8, qc[u]);
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a0), qb, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a1), qb, acc1, 0, 0, 0);
+            } else if constexpr (DT == DT_F16) {
+                const f16x8 qb = __builtin_bit_cast(f16x8, qc[u]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0), qb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1), qb, acc1, 0, 0, 0);
             } else {
                 // split f32: chunks of the hi half meet q_hi and q_lo, chunks of the lo half meet q_hi
                 const bf16x8 A0 = __builtin_bit_cast(bf16x8, a0), A1 = __builtin_bit_cast(bf16x8, a1);
@@ -355,6 +392,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         walk(q0, 0); walk(q1, 4); walk(q2, 8); walk(q3, 12);     // ascending row order per lane
     };
 
+    TL(2);
     if (ntiles > 0) stage(0, tile_lo);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -426,6 +464,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     };
     const int t_live = boot ? H : 0;            // steps of the bootstrap tile: lane maximum only
     int t = 0;
+    TL(3);
+#ifdef SSS_TIMELINE
+    int n_rare = 0;
+#endif
     while (t < T) {
         bool rare = false;
         for (; t < T; ++t) {                    // ---- hot loop
@@ -434,12 +476,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             if (t % H == H - 1) tile_end(t / H);
         }
         if (!rare) break;
+#ifdef SSS_TIMELINE
+        ++n_rare;
+#endif
         insert_block(acc0, (int)row0_of_step + 4 * h);
         insert_block(acc1, (int)row0_of_step + 32 + 4 * h);
         if (t % H == H - 1) tile_end(t / H);
         ++t;
     }
 
+    TL(4);
+#ifdef SSS_TIMELINE
+    if (threadIdx.x == 0) g_tl[blockIdx.x * 8 + 6] = (unsigned long long)n_rare;
+#endif
     list_insert<KP>(ls, li, pend_s, pend_i);   // no-op for lanes with an empty slot (-inf)
     // ---- append the real entries to the query's compact candidate array
     if (q_glob < nq) {
@@ -455,7 +504,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             if (nreal == KP) atomicMax(A.maxlast + q_glob, (unsigned long long)make_key(ls[KP - 1], li[KP - 1]));
         }
     }
+    TL(5); TL(7);
 }
+#ifdef SSS_TIMELINE
+extern "C" int sss_debug_timeline(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), (size_t)n * 8);
+}
+#endif
 
 // ------------------------------------------------------------------------------ host side
 int current_device() {
@@ -531,6 +586,10 @@ int launch_scan(int dtype, int d, int tile_rows, const ScanArgs& a, hipStream_t 
         if (rb == 256) return launch_one<256, 128, DT_BF16>(a, st);
         if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_BF16>(a, st) : launch_one<512, 64, DT_BF16>(a, st);
         if (rb == 1024) return launch_one<1024, 64, DT_BF16, 4>(a, st);
+    } else if (dtype == DT_F16) {
+        if (rb == 256) return launch_one<256, 128, DT_F16>(a, st);
+        if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_F16>(a, st) : launch_one<512, 64, DT_F16>(a, st);
+        if (rb == 1024) return launch_one<1024, 64, DT_F16, 4>(a, st);
     } else if (dtype == DT_SPLIT) {
         if (rb == 256) return launch_one<256, 128, DT_SPLIT>(a, st);
         if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_SPLIT>(a, st) : launch_one<512, 64, DT_SPLIT>(a, st);

@@ -90,13 +90,24 @@ __device__ __forceinline__ float elem_to_f32(const void* row, int kk, int dtype)
 //            misses xl*yl + xr*y + (xh + xl)*yr <= 3.03 * 2^-16 |x||y|, and sum |x_k||y_k| <= |q||c|;
 //            the 3d exact products (sum of magnitudes <= 1.016 |q||c|) are accumulated in f32 like
 //            the bf16 case:                        (3.03 * 2^-16 + 3d * 2^-23 * 1.016) * |q| |c|
+//   DT_F16   corpus and query each scaled by a power of two (exact) and rounded to 11 significant
+//            bits; with c^ = c + rc, q^ = q + rq the scan sums c^ . q^ = c.q + rc.q + c^.rq, so by
+//            Cauchy-Schwarz the rounding costs at most Rc |q| + (|c| + Rc) Rq, where Rc = the largest
+//            row residual norm |c^ - c| over the corpus (measured when the image is built, passed in;
+//            worst case 2^-11 |c|) and Rq = this query's residual norm (measured here).  Elements below
+//            the f16 normal range (2^-14 in the scaled domain = 2^-26 of the largest element) add at
+//            most 2^-25 sqrt(d) |q||c| even if the matrix unit flushed them; products of two f16 are
+//            exact in f32 and accumulate like the bf16 case:
+//                         Rc |q| + (|c| + Rc) Rq + (2^-25 sqrt(d) + d * 2^-23) |q| |c|
 // (each with 2 % headroom; |c| <= the corpus' largest row norm).
-__device__ __forceinline__ double err_bound(int d, int scan_dtype, double qnorm, double cmax) {
-    double rel;
-    if (scan_dtype == DT_F32) rel = (double)d * 5.9604644775390625e-08;
-    else if (scan_dtype == DT_BF16) rel = (double)d * 1.1920928955078125e-07;
-    else rel = 3.03 * 1.52587890625e-05 + 3.0 * (double)d * 1.1920928955078125e-07 * 1.016;
-    return rel * qnorm * cmax * 1.02;
+__device__ __forceinline__ double err_bound(int d, int scan_dtype, double qnorm, double cmax, double c_resid, double q_resid) {
+    double b;
+    if (scan_dtype == DT_F32) b = (double)d * 5.9604644775390625e-08 * qnorm * cmax;
+    else if (scan_dtype == DT_BF16) b = (double)d * 1.1920928955078125e-07 * qnorm * cmax;
+    else if (scan_dtype == DT_SPLIT) b = (3.03 * 1.52587890625e-05 + 3.0 * (double)d * 1.1920928955078125e-07 * 1.016) * qnorm * cmax;
+    else b = c_resid * qnorm + (cmax + c_resid) * q_resid +
+             (2.98023223876953125e-08 * sqrt((double)d) + (double)d * 1.1920928955078125e-07) * qnorm * cmax;
+    return b * 1.02;
 }
 
 // Hand the query's state words back zeroed (scan.h: the contract that replaces a per-call memset).
@@ -140,8 +151,12 @@ __device__ __forceinline__ void rank_and_write(const unsigned long long* sel, co
     }
 }
 
+// unscale: what a scan score must be multiplied by to be a score (1 except for DT_F16).  A row outside
+// the candidates has scan score <= the edge's, so its exact score is <= edge * unscale + B; it can
+// neither enter the top k nor tie with the k-th result AFTER the rounding to float32 if that stays
+// below kth by more than one float32 ulp of kth.
 __device__ __forceinline__ int decide_status(unsigned long long edge, unsigned long long maxlast, unsigned tau_o,
-                                             int J, int nvalid, int k, double kth, double B) {
+                                             int J, int nvalid, int k, double kth, double B, double unscale) {
     int st = 0;
     const bool edge_real = edge != 0 && key_id(edge) >= 0;
     if (maxlast > edge) st |= 1;                                  // a full list may hide a contender
@@ -149,9 +164,23 @@ __device__ __forceinline__ int decide_status(unsigned long long edge, unsigned l
         if (!(edge_real && f2ord(key_score(edge)) >= tau_o)) st |= 2;
     }
     if (edge_real && nvalid >= k) {
-        if ((double)key_score(edge) + 2.0 * B >= kth) st |= 4;    // float32 near-tie window reaches the edge
+        const double reach = (double)key_score(edge) * unscale + B + 2.4e-7 * fabs(kth) + 1e-44;
+        if (!(reach < kth)) st |= 4;                              // the error window reaches the k-th result
     }
     return st;
+}
+
+// squared rounding residual of query element v under the DT_F16 scan's scaling + rounding (scan.hip)
+__device__ __forceinline__ double f16_resid2(float v, int sh) {
+    const float back = ldexpf((float)(_Float16)ldexpf(v, sh), -sh);
+    const double r = (double)back - (double)v;
+    return r * r;
+}
+
+// 2^-(corpus shift + query shift) of a DT_F16 scan (scan.h), from the query row's largest magnitude
+__device__ __forceinline__ double scan_unscale(const SelectArgs& A, float q_amax) {
+    if (A.scan_dtype != DT_F16) return 1.0;
+    return ldexp(1.0, -(A.corpus_shift + f16_shift(q_amax)));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -221,9 +250,24 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
         resc[c] = acc;
     }
     double qn2 = 0.0;
-    for (int kk = lane; kk < A.d; kk += 64) { const double v = elem_to_f32(qrow, kk, A.dtype); qn2 += v * v; }
+    float q_amax = 0.f;
+    for (int kk = lane; kk < A.d; kk += 64) {
+        const float v = elem_to_f32(qrow, kk, A.dtype);
+        qn2 += (double)v * (double)v;
+        q_amax = fmaxf(q_amax, fabsf(v));
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) qn2 += __shfl_xor(qn2, o);     // only feeds the error BOUND: order-free
+    for (int o = 32; o > 0; o >>= 1) {                              // the norm only feeds the error BOUND: order-free
+        qn2 += __shfl_xor(qn2, o);
+        q_amax = fmaxf(q_amax, __shfl_xor(q_amax, o));
+    }
+    double rq2 = 0.0;
+    if (A.scan_dtype == DT_F16) {
+        const int sh = f16_shift(q_amax);
+        for (int kk = lane; kk < A.d; kk += 64) rq2 += f16_resid2(elem_to_f32(qrow, kk, A.dtype), sh);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rq2 += __shfl_xor(rq2, o);
+    }
     wave_sync();
     rank_and_write<64>(sel, resc, K2, k, A.id_offset, Dq, Iq, lane, s_nvalid, s_kth);
     wave_sync();
@@ -236,9 +280,64 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     const unsigned long long maxlast = A.maxlast[q];
     wave_sync();                                                  // every lane has read the state words
     clear_state(A, q, lane, 64);
+    const double B = err_bound(A.d, A.scan_dtype, sqrt(qn2), (double)A.corpus_max_norm, (double)A.corpus_resid, sqrt(rq2));
+    const double unscale = scan_unscale(A, q_amax);
+    int st = decide_status(sel[K2 - 1], maxlast, tau_o, A.J, nvalid, k, *s_kth, B, unscale);
+    // ---- second chance for a query whose ONLY problem is the near-tie window (status 4): the pool
+    // usually holds more candidates than the K2 the threshold certifies, and it is complete down to
+    // max(threshold, largest tail of a full list).  Take up to FS_K2 of them from that region,
+    // re-score the new ones, rank again; what stays outside is bounded by the first key not taken
+    // (or by the region's floor), which lies further below the k-th result.
+    if (st == 4 && K2 < FS_K2) {                                  // wave-uniform (all lanes computed st)
+        const bool has_tau = A.J > 0 && tau_o > ORD_NEG_INF;
+        int K2x = K2;
+        float edge_score = -INFINITY;
+        bool open_end = false;                                    // stopped by the budget: edge = last key taken
+        for (; K2x < FS_K2; ++K2x) {
+            const unsigned long long w = wave_max_u64(best);
+            const bool inside = w != 0 && key_id(w) >= 0 && w >= maxlast && (!has_tau || f2ord(key_score(w)) >= tau_o);
+            if (!inside) {
+                if (w != 0 && key_id(w) >= 0) edge_score = key_score(w);
+                break;
+            }
+            if (lane == 0) sel[K2x] = w;
+            if (best == w) {
+                keys[bidx] = 0;
+                best = 0; bidx = -1;
+                for (int i = lane; i < M; i += 64) {
+                    const unsigned long long v = keys[i];
+                    if (v > best) { best = v; bidx = i; }
+                }
+            }
+        }
+        if (K2x == FS_K2) open_end = true;
+        wave_sync();
+        if (K2x > K2) {
+            for (int c = K2 + lane; c < K2x; c += 64) {
+                const unsigned long long key = sel[c];
+                const char* row = reinterpret_cast<const char*>(A.C) + (size_t)key_id(key) * rb;
+                double acc = 0.0;
+#pragma unroll 8
+                for (int v = 0; v < nv; ++v)
+                    acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
+                resc[c] = acc;
+            }
+            if (lane == 0) { *s_nvalid = 0; *s_kth = 0.0; }
+            wave_sync();
+            rank_and_write<64>(sel, resc, K2x, k, A.id_offset, Dq, Iq, lane, s_nvalid, s_kth);
+            wave_sync();
+            if (open_end) {
+                edge_score = key_score(sel[K2x - 1]);
+            } else {                                              // everything else lies under the region's floor
+                if (has_tau) edge_score = fmaxf(edge_score, ord2f(tau_o - 1));
+                if (maxlast != 0 && key_id(maxlast) >= 0) edge_score = fmaxf(edge_score, key_score(maxlast));
+            }
+            const double kth = *s_kth;
+            const double reach = (double)edge_score * unscale + B + 2.4e-7 * fabs(kth) + 1e-44;
+            st = (*s_nvalid >= k && reach < kth) ? 0 : 4;
+        }
+    }
     if (lane == 0) {
-        const double B = err_bound(A.d, A.scan_dtype, sqrt(qn2), (double)A.corpus_max_norm);
-        const int st = decide_status(sel[K2 - 1], maxlast, tau_o, A.J, nvalid, k, *s_kth, B);
         A.status[q] = st;
         if (st && A.unproven_count) atomicAdd(A.unproven_count, 1);
     }
@@ -254,6 +353,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
     __shared__ int s_nvalid;
     __shared__ double s_kth;
     __shared__ double s_q2[SORT_THREADS / 64];
+    __shared__ float s_amax[SORT_THREADS / 64];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
     const int K2 = A.K2, k = A.k;
@@ -283,10 +383,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
     }
     // ---- float64 re-score straight from global (one thread per candidate, sequential in k)
     double q2 = 0.0;
-    for (int kx = tid; kx < A.d; kx += SORT_THREADS) { const double v = elem_to_f32(qrow, kx, A.dtype); q2 += v * v; }
+    float q_amax = 0.f;
+    for (int kx = tid; kx < A.d; kx += SORT_THREADS) {
+        const float v = elem_to_f32(qrow, kx, A.dtype);
+        q2 += (double)v * (double)v;
+        q_amax = fmaxf(q_amax, fabsf(v));
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
-    if (lane == 0) s_q2[tid >> 6] = q2;
+    for (int o = 32; o > 0; o >>= 1) { q2 += __shfl_xor(q2, o); q_amax = fmaxf(q_amax, __shfl_xor(q_amax, o)); }
+    if (lane == 0) { s_q2[tid >> 6] = q2; s_amax[tid >> 6] = q_amax; }
     for (int c = tid; c < K2; c += SORT_THREADS) {
         const unsigned long long key = keys[c];
         const int id = key_id(key);
@@ -313,9 +418,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
         clear_state(A, q, lane, 64);
         if (tid == 0) {
             double qq = 0.0;
-            for (int w = 0; w < SORT_THREADS / 64; ++w) qq += s_q2[w];
-            const double B = err_bound(A.d, A.scan_dtype, sqrt(qq), (double)A.corpus_max_norm);
-            const int st = decide_status(keys[K2 - 1], maxlast, tau_o, A.J, nvalid, k, s_kth, B);
+            float am = 0.f;
+            for (int w = 0; w < SORT_THREADS / 64; ++w) { qq += s_q2[w]; am = fmaxf(am, s_amax[w]); }
+            double rq2 = 0.0;
+            if (A.scan_dtype == DT_F16) {
+                const int sh = f16_shift(am);
+                for (int kx = 0; kx < A.d; ++kx) rq2 += f16_resid2(elem_to_f32(qrow, kx, A.dtype), sh);
+            }
+            const double B = err_bound(A.d, A.scan_dtype, sqrt(qq), (double)A.corpus_max_norm, (double)A.corpus_resid, sqrt(rq2));
+            const int st = decide_status(keys[K2 - 1], maxlast, tau_o, A.J, nvalid, k, s_kth, B, scan_unscale(A, am));
             A.status[q] = st;
             if (st && A.unproven_count) atomicAdd(A.unproven_count, 1);
         }

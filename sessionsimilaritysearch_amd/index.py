@@ -20,6 +20,8 @@ import torch
 from . import _lib
 
 FUSED_DIMS = {"f32": (64, 128, 256), "bf16": (128, 256, 512)}   # row bytes 256 / 512 / 1024
+F16_SCAN_DIMS = (128, 256, 512)                                  # scaled-f16 image: 2 bytes per element
+AUTO_F16_MAX_K = 16     # scan="auto": k up to this uses the one-pass f16 scan, larger k the bf16 split scan
 FUSED_MAX_K = 500
 DTYPE_CODE = {"f32": 0, "bf16": 1}                               # include/sss.h: dtype
 _EXHAUSTIVE_WS_BYTES = 1 << 30
@@ -99,10 +101,16 @@ class FlatIndex:
     (float64 dot of the stored bf16 values).
 
     ``scan`` picks how a float32 index finds its candidates (the results are the same, they are
-    re-scored from the float32 rows and proven per query either way): ``"split"`` (default) keeps
-    a second image of the corpus, each element as a bfloat16 hi/lo pair (same bytes as the f32
-    row), and scans it with three bf16 MFMA passes -- 16/3 of the f32 matrix rate;
-    ``"f32"`` scans the float32 rows on the f32 MFMA and needs no second image."""
+    re-scored from the float32 rows and proven per query either way; what differs is speed and how
+    many near-tied queries are left to the exhaustive fallback):
+    ``"f16"`` keeps a float16 image of the corpus scaled by one power of two (half the bytes) and
+    scans it with ONE f16 MFMA pass -- score error ~4e-4 |q||c| at d = 128 (d in 128/256/512);
+    ``"split"`` keeps each element as a bfloat16 hi/lo pair (same bytes as the f32 row) and scans
+    with three bf16 MFMA passes -- error <= ~2^-14 |q||c|;
+    ``"f32"`` scans the float32 rows on the f32 MFMA (error ~ d 2^-24) and needs no second image;
+    ``"auto"`` (default) takes "f16" for k <= 16 where the shape allows and "split" otherwise
+    (for large k the k-th scores lie too close together for the f16 bound).  Images are built on
+    first use (``prepare(k)`` does it ahead of time) and extended as rows are added."""
 
     def __init__(self, d: int, metric: str = "ip", device=None, dtype: str = "f32", scan: str | None = None):
         if metric not in ("ip", "l2"):
@@ -112,16 +120,25 @@ class FlatIndex:
         if dtype == "bf16" and d % 8:
             raise ValueError("bf16 index needs d % 8 == 0")
         if scan is None:
-            scan = "split" if dtype == "f32" else "native"
-        if scan not in (("split", "f32") if dtype == "f32" else ("native",)):
-            raise ValueError("scan must be 'split' or 'f32' for a float32 index")
-        self.scan = scan if (metric == "ip" and d in FUSED_DIMS[dtype]) else ("f32" if dtype == "f32" else "native")
-        self._split = None              # [cap, 2d] bf16 hi|lo image of _store (scan == "split")
+            scan = "auto" if dtype == "f32" else "native"
+        if scan not in (("auto", "f16", "split", "f32") if dtype == "f32" else ("native",)):
+            raise ValueError("scan must be 'auto', 'f16', 'split' or 'f32' for a float32 index")
+        self.scan = scan
+        self.last_scan = None           # the scan the last fused search used
         self.d = int(d)
         self.metric = metric
         self.dtype = dtype
         self._tdtype = torch.float32 if dtype == "f32" else torch.bfloat16
         self.device = _dev(device)
+        # derived corpus images, built on first use and extended as rows are added
+        self._split = None              # [cap, 2d] bf16 hi|lo image of the rows        ("split" scan)
+        self._split_done = 0            # rows of it that are valid
+        self._f16 = None                # [cap, d] float16 image of rows * 2^_c_shift  ("f16" scan)
+        self._f16_done = 0
+        self._c_shift = 0
+        self._amax_t = torch.zeros(1, dtype=torch.float32, device=self.device)    # largest |element| in the f16 image
+        self._resid_t = torch.zeros(1, dtype=torch.float32, device=self.device)   # largest row residual norm of it
+        self._resid = None
         self._xb = torch.empty((0, self.d), dtype=self._tdtype, device=self.device)
         self._store = self._xb          # backing storage of _xb (grown geometrically by add())
         self._cmax_t = torch.zeros(1, dtype=torch.float32, device=self.device)
@@ -144,26 +161,81 @@ class FlatIndex:
             store = torch.empty((cap, self.d), dtype=self._tdtype, device=self.device)
             store[:n_old] = self._xb
             self._store = store
-            if self.scan == "split":
-                split = torch.empty((cap, 2 * self.d), dtype=torch.bfloat16, device=self.device)
-                if n_old:
-                    split[:n_old] = self._split[:n_old]
-                self._split = split
         self._store[n_old:n_old + x.shape[0]] = x
         self._xb = self._store[:n_old + x.shape[0]]
-        if self.scan == "split":
-            self._split_rows(n_old, x.shape[0])
         self._norm_max(x)
 
-    def _split_rows(self, lo: int, count: int):
-        """(Re)build rows [lo, lo + count) of the hi|lo bf16 image from the float32 rows."""
-        if self._split is None or self._split.shape[0] < lo + count:
-            self._split = torch.empty((self._store.shape[0], 2 * self.d), dtype=torch.bfloat16, device=self.device)
-            lo, count = 0, self.ntotal
-        if count:
-            rc = _lib.lib().sss_split_bf16(self._xb[lo:].data_ptr(), count, self.d, self._split[lo:].data_ptr(),
-                                           _lib.stream_ptr(self.device))
-            _lib.check(rc, "sss_split_bf16")
+    def scan_for(self, k: int) -> str:
+        """Which candidate scan a fused search for k results uses ("" = none: exhaustive path)."""
+        if self.metric != "ip" or not (0 < k <= FUSED_MAX_K) or self.ntotal == 0:
+            return ""
+        if self.dtype != "f32":
+            return "native" if self.d in FUSED_DIMS[self.dtype] else ""
+        want = self.scan
+        if want == "auto":
+            want = "f16" if k <= AUTO_F16_MAX_K else "split"
+        if want == "f16" and self.d not in F16_SCAN_DIMS:
+            want = "split"
+        return want if (want == "f16" or self.d in FUSED_DIMS["f32"]) else ""
+
+    def _grow_image(self, img, done, width, tdtype):
+        """The image tensor with room for every row of the store, its first `done` rows kept."""
+        if img is None or img.shape[0] < self._store.shape[0] or img.shape[0] < self.ntotal:
+            new = torch.empty((max(self._store.shape[0], self.ntotal), width), dtype=tdtype, device=self.device)
+            if img is not None and done:
+                new[:done] = img[:done]
+            img = new
+        return img
+
+    def _ensure_f16(self):
+        """Bring the scaled float16 image up to date.  Its shift is fixed by the largest |element|
+        present when it was last rebuilt (which then lies in [2^12, 2^13)); rows that would push an
+        element past 2^15 trigger a rebuild of the whole image with a new shift."""
+        n, lo = self.ntotal, self._f16_done
+        if lo == n and self._f16 is not None:
+            return
+        L, st = _lib.lib(), _lib.stream_ptr(self.device)
+        _lib.check(L.sss_abs_max(self._xb[lo:].data_ptr(), (n - lo) * self.d, self._amax_t.data_ptr(), st), "sss_abs_max")
+        amax = float(self._amax_t.item())
+        self._f16 = self._grow_image(self._f16, lo, self.d, torch.float16)
+        if lo == 0 or not (amax * 2.0 ** self._c_shift < 32768.0):
+            self._c_shift = int(L.sss_f16_shift(amax))
+            self._resid_t.zero_()
+            lo = 0
+        _lib.check(L.sss_scale_f16(self._xb[lo:].data_ptr(), (n - lo) * self.d, self._c_shift,
+                                   self._f16[lo:].data_ptr(), st), "sss_scale_f16")
+        _lib.check(L.sss_f16_resid_max(self._xb[lo:].data_ptr(), self._f16[lo:].data_ptr(), n - lo, self.d,
+                                       self._c_shift, self._resid_t.data_ptr(), st), "sss_f16_resid_max")
+        self._resid = None
+        self._f16_done = n
+
+    def corpus_resid_norm(self) -> float:
+        if self._resid is None:
+            self._resid = float(self._resid_t.item())
+        return self._resid
+
+    def _ensure_split(self):
+        """Bring the bf16 hi|lo image up to date."""
+        n, lo = self.ntotal, self._split_done
+        if lo == n and self._split is not None:
+            return
+        self._split = self._grow_image(self._split, lo, 2 * self.d, torch.bfloat16)
+        rc = _lib.lib().sss_split_bf16(self._xb[lo:].data_ptr(), n - lo, self.d, self._split[lo:].data_ptr(),
+                                       _lib.stream_ptr(self.device))
+        _lib.check(rc, "sss_split_bf16")
+        self._split_done = n
+
+    def prepare(self, k: int = 10):
+        """Build whatever a fused search for k results needs (images, norms) now rather than on
+        the first search; returns the scan that will be used."""
+        mode = self.scan_for(k)
+        if mode == "f16":
+            self._ensure_f16()
+            self.corpus_resid_norm()
+        elif mode == "split":
+            self._ensure_split()
+        self.corpus_max_norm()
+        return mode
 
     def _rows(self, x, what):
         """Input rows as a contiguous device tensor of the index's element type."""
@@ -194,9 +266,10 @@ class FlatIndex:
         self.id_offset = int(id_offset)
         self._cmax_t.zero_()
         self._norm_max(xb)
-        if self.scan == "split":
-            self._split = None
-            self._split_rows(0, xb.shape[0])
+        self._split, self._split_done = None, 0
+        self._f16, self._f16_done = None, 0
+        self._amax_t.zero_()
+        self._resid_t.zero_()
         return self
 
     def corpus_max_norm(self) -> float:
@@ -211,7 +284,7 @@ class FlatIndex:
         return self._ws
 
     def fused_ok(self, k: int) -> bool:
-        return self.metric == "ip" and self.d in FUSED_DIMS[self.dtype] and 0 < k <= FUSED_MAX_K and self.ntotal > 0
+        return self.scan_for(k) != ""
 
     def search_fused(self, q: torch.Tensor, k: int, out=None, unproven_count=None):
         """Enqueue the fused MFMA scoring + top-k on the current stream; no host sync.
@@ -227,7 +300,13 @@ class FlatIndex:
             status = torch.empty((nq,), dtype=torch.int32, device=self.device)
         else:
             D, I, status = out
-        nbytes = L.sss_ip_topk_workspace_bytes(nq, n, self.d, k, DTYPE_CODE[self.dtype])
+        mode = self.last_scan = self.prepare(k)
+        if mode == "":
+            raise _lib.SssError("search_fused: this index / k has no fused path (use search)")
+        if mode == "f16":
+            nbytes = L.sss_ip_topk_f16_workspace_bytes(nq, n, self.d, k)
+        else:
+            nbytes = L.sss_ip_topk_workspace_bytes(nq, n, self.d, k, DTYPE_CODE[self.dtype])
         ws = self._workspace(nbytes)
         sbytes = L.sss_ip_topk_state_bytes(nq)
         if self._state is None or self._state.numel() < sbytes:
@@ -235,7 +314,10 @@ class FlatIndex:
         tail = (self.corpus_max_norm(), D.data_ptr(), I.data_ptr(), status.data_ptr(),
                 0 if unproven_count is None else unproven_count.data_ptr(),
                 self._state.data_ptr(), self._state.numel(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
-        if self.scan == "split":
+        if mode == "f16":
+            rc = L.sss_ip_topk_f16(q.data_ptr(), nq, self._xb.data_ptr(), self._f16.data_ptr(), self._c_shift,
+                                   self.corpus_resid_norm(), n, self.d, k, self.id_offset, *tail)
+        elif mode == "split":
             rc = L.sss_ip_topk_split(q.data_ptr(), nq, self._xb.data_ptr(), self._split.data_ptr(), n, self.d, k,
                                      self.id_offset, *tail)
         else:

@@ -24,10 +24,11 @@ def _index(c, cuda, metric="ip", scan=None):
     return idx
 
 
-@pytest.fixture(params=["split", "f32"])
+@pytest.fixture(params=["f16", "split", "f32"])
 def scan(request):
-    """Both candidate scans of a float32 index: bf16 hi/lo split (3 bf16 MFMA passes, the default)
-    and the f32 MFMA.  Results must be identical (and equal to the oracle) either way."""
+    """The candidate scans of a float32 index: scaled float16 image (one f16 MFMA pass; the default
+    for d >= 128), bf16 hi/lo split (three bf16 MFMA passes; the default for d = 64) and the f32
+    MFMA.  Results must be identical (and equal to the oracle) whichever found the candidates."""
     return request.param
 
 
@@ -275,10 +276,16 @@ def test_config_c4_10m_rows(cuda):
     idx = FlatIndex(d, "ip", cuda, scan="f32").adopt(c)
     D, I, status = idx.search_fused(q, k)
     assert int(status.sum().item()) == 0
-    idx = FlatIndex(d, "ip", cuda, scan="split").adopt(c)      # the default scan: same results, also all proven
+    idx = FlatIndex(d, "ip", cuda, scan="split").adopt(c)     # bf16 split scan: same results, also all proven
     D2, I2, status2 = idx.search_fused(q, k)
     assert int(status2.sum().item()) == 0
     assert torch.equal(I2, I) and torch.equal(D2, D)
+    # one-pass f16 scan (the default at k = 10): its coarser bound may leave a handful of near-ties to
+    # the exact fallback -- the answer must not change
+    idx = FlatIndex(d, "ip", cuda).adopt(c)
+    D3, I3 = idx.search_device(q, k)
+    assert idx.last_scan == "f16" and idx.last_fallback_queries <= 8
+    assert torch.equal(I3, I) and torch.equal(D3, D)
     Dn, In = D.cpu().numpy(), I.cpu().numpy()
     assert (np.diff(Dn, axis=1) <= 0).all() and (In >= 0).all() and (In < n).all()
     assert all(len(set(r.tolist())) == k for r in In)
@@ -287,8 +294,8 @@ def test_config_c4_10m_rows(cuda):
     for s in range(8):
         lo, hi = s * n // 8, (s + 1) * n // 8
         sh = FlatIndex(d, "ip", cuda).adopt(c[lo:hi], id_offset=lo)
-        d_s, i_s, st_s = sh.search_fused(q, k)
-        assert int(st_s.sum().item()) == 0
+        d_s, i_s = sh.search_device(q, k)                 # default scan (f16) + exact fallback for unproven queries
+        assert sh.last_fallback_queries <= 8
         Ds.append(d_s.clone()); Is.append(i_s.clone())
     Din, Iin = torch.stack(Ds).contiguous(), torch.stack(Is).contiguous()
     Dm, Im = torch.empty_like(D), torch.empty_like(I)
@@ -339,6 +346,74 @@ def test_split_scan_near_ties_inside_its_error_bound(cuda):
     # the f32 scan resolves these scores: same answer
     D2, I2 = _index(c, cuda, scan="f32").search(q, 10)
     assert np.array_equal(I2, Ir) and np.array_equal(D2, Dr)
+
+
+def test_scaled_f16_image_is_exact_scaling_then_one_rounding(cuda):
+    """sss_abs_max / sss_f16_shift / sss_scale_f16: y = rne_f16(x * 2^shift), largest element in [2^12, 2^13)."""
+    from sessionsimilaritysearch_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(72)
+    for scale in (1.0, 3.7e-9, 2.9e7):
+        x = (rng.standard_normal((257, 128)) * scale).astype(np.float32)
+        tx = torch.from_numpy(x).to(cuda)
+        am = torch.zeros(1, device=cuda)
+        _lib.check(L.sss_abs_max(tx.data_ptr(), tx.numel(), am.data_ptr(), _lib.stream_ptr(cuda)), "abs_max")
+        amax = float(am.item())
+        assert amax == float(np.abs(x).max())
+        sh = L.sss_f16_shift(amax)
+        assert 4096.0 <= amax * 2.0 ** sh < 8192.0
+        y = torch.empty((257, 128), dtype=torch.float16, device=cuda)
+        _lib.check(L.sss_scale_f16(tx.data_ptr(), tx.numel(), sh, y.data_ptr(), _lib.stream_ptr(cuda)), "scale")
+        ref = torch.from_numpy(np.ldexp(x.astype(np.float64), sh)).to(torch.float16)
+        assert torch.equal(y.cpu(), ref)
+    assert L.sss_f16_shift(0.0) == 0 and L.sss_f16_shift(float("inf")) == 0
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-7, 5e5])
+def test_f16_scan_on_unnormalised_vectors(cuda, scale):
+    """Inner-product metric on vectors far from unit norm (and wildly different norms per row):
+    the per-corpus and per-query power-of-two scaling keeps the f16 scan inside its range."""
+    rng = np.random.default_rng(73)
+    c = (rng.standard_normal((40000, 128)) * scale * np.exp(rng.uniform(-3, 3, (40000, 1)))).astype(np.float32)
+    q = (rng.standard_normal((200, 128)) * np.exp(rng.uniform(-8, 8, (200, 1)))).astype(np.float32)
+    idx = _index(c, cuda, scan="f16")
+    D, I = idx.search(q, 10)
+    assert idx.last_scan == "f16"
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    assert idx.last_fallback_queries <= 20
+
+
+def test_f16_image_rescales_when_larger_rows_arrive(cuda):
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(74)
+    a = _unit(rng, 3000, 128)
+    b = (_unit(rng, 3000, 128) * 37.0).astype(np.float32)          # > 4x the largest element so far: new shift
+    c2 = (_unit(rng, 500, 128) * 1.5).astype(np.float32)           # within the head-room: appended in place
+    idx = FlatIndex(128, "ip", cuda, scan="f16")
+    idx.add(a); idx.prepare(10); s0 = idx._c_shift
+    idx.add(c2); idx.prepare(10); assert idx._c_shift == s0 and idx._f16_done == 3500
+    idx.add(b); idx.prepare(10); assert idx._c_shift < s0 and idx._f16_done == 6500
+    c = np.concatenate([a, c2, b])
+    q = _unit(rng, 64, 128)
+    D, I = idx.search(q, 10)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_f16_scan_near_ties_inside_its_error_bound(cuda):
+    """Clusters whose scores differ by ~1e-5: resolved by the f32 rows, invisible to one f16 pass
+    (bound ~1e-3 |q||c|).  The proof must send them to the exact fallback; the answer is the oracle's."""
+    rng = np.random.default_rng(75)
+    base = _unit(rng, 1500, 128)
+    c = np.repeat(base, 40, axis=0) + (rng.standard_normal((60000, 128)) * 2e-5).astype(np.float32)
+    c = np.ascontiguousarray(c[rng.permutation(60000)]).astype(np.float32)
+    q = _unit(rng, 96, 128)
+    idx = _index(c, cuda, scan="f16")
+    D, I = idx.search(q, 10)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    assert idx.last_fallback_queries > 0
 
 
 # ----------------------------------------------------------------------------------------------
@@ -405,7 +480,28 @@ def test_large_k_500_matches_oracle(cuda, scan):
     D, I = idx.search(q, 500)
     Dr, Ir = sr.search_exact(q, c, 500)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
-    assert idx.last_fallback_queries <= 64
+    if scan != "f16":          # (forced f16 at k = 500: neighbouring scores lie inside its bound, most queries fall back;
+        assert idx.last_fallback_queries <= 64          # scan="auto" uses the split scan there)
+
+
+def test_auto_scan_picks_by_k_and_shape(cuda):
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(76)
+    c, q = _unit(rng, 9000, 128), _unit(rng, 40, 128)
+    idx = FlatIndex(128, "ip", cuda)
+    idx.add(c)
+    for k, want in ((10, "f16"), (16, "f16"), (100, "split")):
+        D, I = idx.search(q, k)
+        assert idx.last_scan == want
+        Dr, Ir = sr.search_exact(q, c, k)
+        assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    c64, q64 = _unit(rng, 5000, 64), _unit(rng, 40, 64)
+    idx = FlatIndex(64, "ip", cuda)
+    idx.add(c64)
+    D, I = idx.search(q64, 10)
+    assert idx.last_scan == "split"
+    Dr, Ir = sr.search_exact(q64, c64, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
 def test_index_add_in_pieces_equals_single_add(cuda):
