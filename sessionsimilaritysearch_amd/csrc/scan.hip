@@ -30,6 +30,7 @@
 //   * at the end each lane appends its real entries to the query's compact candidate array
 //     (one atomic add per lane) for k_select_* (select.hip).
 #include "scan.h"
+#include <cstdlib>
 
 namespace sss {
 
@@ -90,10 +91,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     constexpr int TILE_BYTES = TR * RB;
     constexpr int LOADS_PER_WAVE = TR * CH / 64 / NW; // LDS-DMA wave-instructions per wave per tile
     constexpr int WGQ = NW * 32;                      // queries per workgroup
-    constexpr bool PRECOMP = RB <= 512;               // keep the DMA lane offsets in VGPRs (register budget)
+    constexpr bool MULTI = LOADS_PER_WAVE > NU - 1;   // a tile's DMA pieces do not fit one sub-step's k loop: spread over sub-steps
+    constexpr bool PRECOMP = RB <= 512 && !MULTI;     // keep the DMA lane offsets in VGPRs (register budget; compile-time piece index)
     constexpr int TAU_LDS = 2 * TILE_BYTES;           // [8 waves][32 queries][16 slots] u32 behind the two tile buffers
     static_assert(CH <= 64, "row longer than one LDS-DMA instruction");
-    static_assert(LOADS_PER_WAVE >= 1 && LOADS_PER_WAVE < NU, "DMA pieces must fit the k loop");
+    static_assert(LOADS_PER_WAVE >= 1 && LOADS_PER_WAVE <= (MULTI ? H : 1) * (NU - 1), "DMA pieces must fit the k loops");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int nq = A.nq, n = A.n, S = A.S, G = A.G, J = A.J;
@@ -307,13 +309,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             const int c = (2 * u) ^ x;                          // == (2u + h) ^ (r & 15)
             return *reinterpret_cast<const f32x4*>(tile + ((r + 32 * mb) * CH + c) * 16);
         };
-        f32x4 a0 = lda(0, 0), a1 = lda(0, 1);
+        // A fragments PF k-groups ahead of their MFMAs: the f32 MFMA spends 512 cycles on a group, one
+        // group ahead covers the LDS latency; the 16-bit MFMAs spend 64-128, so their reads run further
+        // ahead (all of a 256-byte row's fragments at once -- the registers are there).
+        constexpr int PF = DT == DT_F32 ? 1 : (RB == 256 ? NU : RB == 512 ? 4 : 2);
+        f32x4 as0[NU], as1[NU];
+#pragma unroll
+        for (int u = 0; u < PF && u < NU; ++u) { as0[u] = lda(u, 0); as1[u] = lda(u, 1); }
         const f32x16 zero = {0};
         acc0 = zero; acc1 = zero;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            f32x4 n0 = a0, n1 = a1;
-            if (u + 1 < NU) { n0 = lda(u + 1, 0); n1 = lda(u + 1, 1); }   // one k-group ahead
+            if (u + PF < NU) { as0[u + PF] = lda(u + PF, 0); as1[u + PF] = lda(u + PF, 1); }
+            const f32x4 a0 = as0[u], a1 = as1[u];
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE this group's MFMAs
             if constexpr (DT == DT_F32) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, qc[u].x, acc0, 0, 0, 0);
@@ -345,11 +353,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            a0 = n0; a1 = n1;
             // one DMA piece per k-group: each issue hides under the MFMAs this wave just queued
-            if (u >= 1 && u - 1 < LOADS_PER_WAVE && next_tile >= 0) {
-                stage_piece(buf ^ 1, next_tile, u - 1);
-                __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!MULTI) {
+                if (u >= 1 && u - 1 < LOADS_PER_WAVE && sub == 0 && next_tile >= 0) {
+                    stage_piece(buf ^ 1, next_tile, u - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                if (u >= 1) {
+                    const int piece = sub * (NU - 1) + (u - 1);        // wave-uniform, runtime (sub is)
+                    if (piece < LOADS_PER_WAVE && next_tile >= 0) stage_piece(buf ^ 1, next_tile, piece);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     };
@@ -442,7 +457,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     auto score_step = [&](int t) -> float {
         const int i = t / H, sub = t % H;
         if (sub == 0) tile_top(i);
-        const int next_tile = (sub == 0 && i + 1 < niter) ? tile_of(i + 1) : -1;
+        const int next_tile = (i + 1 < niter) ? tile_of(i + 1) : -1;
         mfma_sub(i & 1, sub, next_tile);
         row0_of_step = (long)tile_of(i) * TR + sub * 64;
         if (row0_of_step + 64 > n) {                        // wave-uniform, last tile only
@@ -527,6 +542,12 @@ static int pick_splits(long n, int G, int tr) {
     return S;
 }
 
+static int tr256_min_tiles() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SSS_TR256_MIN_TILES"); v = e ? atoi(e) : 24; }
+    return v;
+}
+
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
@@ -539,6 +560,9 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     int tr = rb <= 512 ? 128 : 64;
     int S = pick_splits(n, p.G, tr);
     if (rb == 512 && (n + (long)S * 128 - 1) / ((long)S * 128) < 48) { tr = 64; S = pick_splits(n, p.G, tr); }
+    // 256-byte rows: 256-row tiles (one barrier and one threshold refresh per 256 rows, the next tile's
+    // DMA a whole tile ahead) once a split is long enough to amortise the twice-scanned bootstrap tile
+    if (rb == 256 && dtype != DT_F32 && n / ((long)S * 256) >= tr256_min_tiles()) tr = 256;
     p.tile_rows = tr;
     p.S = S;
     p.L = 2 * S;
@@ -579,19 +603,19 @@ static int launch_one(const ScanArgs& a, hipStream_t st) {
 int launch_scan(int dtype, int d, int tile_rows, const ScanArgs& a, hipStream_t st) {
     const int rb = d * elem_bytes(dtype);
     if (dtype == DT_F32) {
-        if (rb == 256) return launch_one<256, 128, DT_F32>(a, st);
+        if (rb == 256) return tile_rows == 256 ? launch_one<256, 256, DT_F32>(a, st) : launch_one<256, 128, DT_F32>(a, st);
         if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_F32>(a, st) : launch_one<512, 64, DT_F32>(a, st);
         if (rb == 1024) return launch_one<1024, 64, DT_F32, 4>(a, st);
     } else if (dtype == DT_BF16) {
-        if (rb == 256) return launch_one<256, 128, DT_BF16>(a, st);
+        if (rb == 256) return tile_rows == 256 ? launch_one<256, 256, DT_BF16>(a, st) : launch_one<256, 128, DT_BF16>(a, st);
         if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_BF16>(a, st) : launch_one<512, 64, DT_BF16>(a, st);
         if (rb == 1024) return launch_one<1024, 64, DT_BF16, 4>(a, st);
     } else if (dtype == DT_F16) {
-        if (rb == 256) return launch_one<256, 128, DT_F16>(a, st);
+        if (rb == 256) return tile_rows == 256 ? launch_one<256, 256, DT_F16>(a, st) : launch_one<256, 128, DT_F16>(a, st);
         if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_F16>(a, st) : launch_one<512, 64, DT_F16>(a, st);
         if (rb == 1024) return launch_one<1024, 64, DT_F16, 4>(a, st);
     } else if (dtype == DT_SPLIT) {
-        if (rb == 256) return launch_one<256, 128, DT_SPLIT>(a, st);
+        if (rb == 256) return tile_rows == 256 ? launch_one<256, 256, DT_SPLIT>(a, st) : launch_one<256, 128, DT_SPLIT>(a, st);
         if (rb == 512) return tile_rows == 128 ? launch_one<512, 128, DT_SPLIT>(a, st) : launch_one<512, 64, DT_SPLIT>(a, st);
         if (rb == 1024) return launch_one<1024, 64, DT_SPLIT, 4>(a, st);
     }
