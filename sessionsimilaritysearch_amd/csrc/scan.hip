@@ -91,11 +91,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     constexpr int TILE_BYTES = TR * RB;
     constexpr int LOADS_PER_WAVE = TR * CH / 64 / NW; // LDS-DMA wave-instructions per wave per tile
     constexpr int WGQ = NW * 32;                      // queries per workgroup
-    constexpr bool MULTI = LOADS_PER_WAVE > NU - 1;   // a tile's DMA pieces do not fit one sub-step's k loop: spread over sub-steps
-    constexpr bool PRECOMP = RB <= 512 && !MULTI;     // keep the DMA lane offsets in VGPRs (register budget; compile-time piece index)
+    constexpr bool PRECOMP = RB <= 512;               // keep the DMA lane offsets in VGPRs (register budget)
     constexpr int TAU_LDS = 2 * TILE_BYTES;           // [8 waves][32 queries][16 slots] u32 behind the two tile buffers
     static_assert(CH <= 64, "row longer than one LDS-DMA instruction");
-    static_assert(LOADS_PER_WAVE >= 1 && LOADS_PER_WAVE <= (MULTI ? H : 1) * (NU - 1), "DMA pieces must fit the k loops");
+    static_assert(LOADS_PER_WAVE >= 1, "a tile is at least one DMA piece per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int nq = A.nq, n = A.n, S = A.S, G = A.G, J = A.J;
@@ -305,9 +304,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
 
     auto mfma_sub = [&](int buf, int sub, int next_tile) {
         const char* tile = smem + buf * TILE_BYTES + sub * (64 * RB);
-        auto lda = [&](int u, int mb) -> f32x4 {
+        // The next tile's DMA (all of this wave's pieces in one burst, once per tile): with a single
+        // sub-step per tile it has to go out before this step's MFMAs to have time to land; otherwise
+        // it follows the first sub-step's MFMAs, issuing while they execute, and has the rest of the
+        // tile to land.  (One piece per k-group, as before, cost ~20 scalar instructions and a branch
+        // per group in every step: the scan was bound by instruction issue, not by the matrix pipe.)
+        if constexpr (H == 1) { if (next_tile >= 0) stage(buf ^ 1, next_tile); }
+        auto lda = [&](int u) -> const f32x4* {
             const int c = (2 * u) ^ x;                          // == (2u + h) ^ (r & 15)
-            return *reinterpret_cast<const f32x4*>(tile + ((r + 32 * mb) * CH + c) * 16);
+            return reinterpret_cast<const f32x4*>(tile + (r * CH + c) * 16);
         };
         // A fragments PF k-groups ahead of their MFMAs: the f32 MFMA spends 512 cycles on a group, one
         // group ahead covers the LDS latency; the 16-bit MFMAs spend 64-128, so their reads run further
@@ -315,12 +320,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         constexpr int PF = DT == DT_F32 ? 1 : (RB == 256 ? NU : RB == 512 ? 4 : 2);
         f32x4 as0[NU], as1[NU];
 #pragma unroll
-        for (int u = 0; u < PF && u < NU; ++u) { as0[u] = lda(u, 0); as1[u] = lda(u, 1); }
+        for (int u = 0; u < PF && u < NU; ++u) { const f32x4* p = lda(u); as0[u] = p[0]; as1[u] = p[32 * CH]; }
         const f32x16 zero = {0};
         acc0 = zero; acc1 = zero;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            if (u + PF < NU) { as0[u + PF] = lda(u + PF, 0); as1[u + PF] = lda(u + PF, 1); }
+            if (u + PF < NU) { const f32x4* p = lda(u + PF); as0[u + PF] = p[0]; as1[u + PF] = p[32 * CH]; }
             const f32x4 a0 = as0[u], a1 = as1[u];
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE this group's MFMAs
             if constexpr (DT == DT_F32) {
@@ -353,20 +358,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            // one DMA piece per k-group: each issue hides under the MFMAs this wave just queued
-            if constexpr (!MULTI) {
-                if (u >= 1 && u - 1 < LOADS_PER_WAVE && sub == 0 && next_tile >= 0) {
-                    stage_piece(buf ^ 1, next_tile, u - 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                if (u >= 1) {
-                    const int piece = sub * (NU - 1) + (u - 1);        // wave-uniform, runtime (sub is)
-                    if (piece < LOADS_PER_WAVE && next_tile >= 0) stage_piece(buf ^ 1, next_tile, piece);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
         }
+        if constexpr (H > 1) { if (sub == 0 && next_tile >= 0) stage(buf ^ 1, next_tile); }
     };
 
     auto block_max = [&](const f32x16& a, float& q0, float& q1, float& q2, float& q3) {
