@@ -48,7 +48,8 @@ sys.path.insert(0, ROOT)
 
 from sessionsimilaritysearch_amd import _lib  # noqa: E402
 from sessionsimilaritysearch_amd import sessions as S  # noqa: E402
-from sessionsimilaritysearch_amd.distributed import HipEngine, ShardedFlatIndex, shard_range  # noqa: E402
+from sessionsimilaritysearch_amd.distributed import (HipEngine, ShardedFlatIndex, gather_query_embeddings,  # noqa: E402
+                                                       query_slice, shard_range)
 from sessionsimilaritysearch_amd.encoder import EncoderConfig, SessionEncoder, init_weights  # noqa: E402
 from sessionsimilaritysearch_amd.index import FlatIndex, normalize_, to_bf16  # noqa: E402
 
@@ -182,14 +183,17 @@ def main():
     if c3:
         q_acts = q_acts.prefix(1, 2)             # the query is a prefix sub-session (test_amazon_filterd.py:546)
     q_host = S.build_batch(q_acts)               # host copy: only the CPU baseline / oracle read it
-    qbatch = enc.prepare_actions(q_acts)         # batched CSR session graph built on device, resident in HBM
+    # every rank embeds nq / world of the query sessions; one all-gather hands everyone the batch
+    q_lo, q_hi = query_slice(nq, world, rank)
+    qbatch = enc.prepare_actions(q_acts.slice(q_lo, q_hi) if (q_lo, q_hi) != (0, nq) else q_acts)   # batched CSR session graph built on device, resident in HBM
+    emb_all = torch.empty((nq, d), dtype=torch.float32, device=device)
     k_items = k
     if c3:
         from sessionsimilaritysearch_amd.retrieval import knn_item_vote
         k = args.sample_size                     # neighbours searched; k_items items voted
 
     def embed():
-        emb = enc(qbatch, l2_normalize=True)
+        emb = gather_query_embeddings(enc(qbatch, l2_normalize=True), nq, emb_all)
         return to_bf16(emb) if args.dtype == "bf16" else emb
 
     def step_async():

@@ -5,8 +5,10 @@ RCCL/xGMI, then a k-way merge on every rank.
 The reference is single-process (no NCCL/MPI call site anywhere); this is the one parallel
 strategy the path needs, and the only collective is that all-gather of ``12 * nq * k`` bytes per
 rank -- latency-bound, so it is a single ``all_gather_into_tensor`` rather than a ring of
-small messages.  Queries are replicated (every rank embeds the same query batch; cheaper than a
-broadcast + sync at 512 KB).
+small messages.  The query batch is embedded cooperatively: every rank embeds nq / world of the
+sessions and one all-gather of ``4 * nq * d`` bytes hands every rank the whole batch
+(``gather_query_embeddings``) -- once the scan takes ~0.1 ms per shard, embedding the full batch on
+every rank would be the Amdahl term of strong scaling.
 
 The local search and the merge are injected (``engine``) so the sharding / packing / gather
 logic can be exercised on CPU with the ``gloo`` backend in the tests; the default engine is the
@@ -23,6 +25,26 @@ def shard_range(n: int, world: int, rank: int):
     base, rem = divmod(n, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def query_slice(nq: int, world: int, rank: int):
+    """Rows of the query batch that ``rank`` embeds; equal sizes (the all-gather needs them), so
+    (0, nq) -- every rank embeds everything -- when world does not divide nq."""
+    if world <= 1 or nq % world:
+        return 0, nq
+    per = nq // world
+    return rank * per, (rank + 1) * per
+
+
+def gather_query_embeddings(emb_local: torch.Tensor, nq: int, out: torch.Tensor | None = None, group=None):
+    """All ranks' [nq / world, d] slices (``query_slice`` order) -> the full [nq, d] batch on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1 or emb_local.shape[0] == nq:
+        return emb_local
+    if out is None:
+        out = torch.empty((nq, emb_local.shape[1]), dtype=emb_local.dtype, device=emb_local.device)
+    dist.all_gather_into_tensor(out, emb_local.contiguous(), group=group)
+    return out
 
 
 class HipEngine:

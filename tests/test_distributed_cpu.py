@@ -14,7 +14,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import search_ref as sr
-from sessionsimilaritysearch_amd.distributed import ShardedFlatIndex, shard_range
+from sessionsimilaritysearch_amd.distributed import (ShardedFlatIndex, gather_query_embeddings, query_slice,
+                                                       shard_range)
 
 
 def test_shard_range_covers_everything():
@@ -25,6 +26,14 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_query_slice_is_an_equal_partition_or_everything():
+    for nq, w in ((1024, 8), (1024, 2), (12, 4), (1, 1)):
+        spans = [query_slice(nq, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == nq and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert len({b - a for a, b in spans}) == 1
+    assert all(query_slice(13, 4, r) == (0, 13) for r in range(4))      # not divisible: every rank embeds the batch
 
 
 class OracleEngine:
@@ -66,6 +75,10 @@ def _worker(rank, world, port, n, k, out_dir):
         Dr, Ir = sr.search_exact(q, c, k, threads=1)
         ok = np.array_equal(I.numpy(), Ir) and np.array_equal(D.numpy(), Dr)
         ok = ok and np.array_equal(I2.numpy(), Ir) and int(st.sum()) == 0
+        # cooperative embedding: each rank holds its query_slice of a 12-row batch, everyone ends with all of it
+        full = torch.arange(12 * 4, dtype=torch.float32).view(12, 4)
+        a, b = query_slice(12, world, rank)
+        ok = ok and torch.equal(gather_query_embeddings(full[a:b].clone(), 12), full)
         open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "MISMATCH")
     finally:
         dist.destroy_process_group()
