@@ -24,16 +24,24 @@ pmc() {     # name, counters, args...
     echo "[$name] done"
 }
 stats bench_default $BENCH
+stats bench_split $BENCH --scan split
+stats bench_f32 $BENCH --scan f32
 stats bench_c4_10m bench.py --steps 10 --warmup 2 --no-cpu-baseline --corpus-rows 10000000 --corpus-source random
+stats bench_c4_10m_f32 bench.py --steps 5 --warmup 2 --no-cpu-baseline --corpus-rows 10000000 --corpus-source random --scan f32
 stats bench_c5_bf16 bench.py --steps 10 --warmup 2 --no-cpu-baseline --corpus-rows 10000000 --corpus-source random --dtype bf16 --d 256 --nq 4096
 stats bench_c3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload c3 --corpus-rows 1000000
 stats encoder scripts/bench_encoder.py 1024
-stats search_shapes scripts/quick_search_bench.py 1024,125000,128,10 1024,1000000,128,10 1024,125000,64,10 1024,125000,128,100
+stats search_shapes scripts/quick_search_bench.py 1024,125000,128,10,f16 1024,1000000,128,10,f16 1024,10000000,128,10,f16 1024,1000000,256,10,f16 1024,125000,128,10,split 1024,1000000,128,10,split 1024,1000000,64,10,split 1024,1000000,128,100,split 1024,125000,128,10,f32mfma 1024,1000000,128,10,f32mfma 1024,125000,64,10,f32mfma 1024,125000,128,100,f32mfma
 PM="bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 pmc pmc_fetch FETCH_SIZE $PM
 pmc pmc_write WRITE_SIZE $PM
-pmc pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" $PM
+pmc pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE" $PM
+pmc pmc_issue "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_BRANCH SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" $PM
 pmc pmc_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" $PM
+pmc pmc_fetch_split FETCH_SIZE $PM --scan split
+pmc pmc_mfma_split "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" $PM --scan split
+pmc pmc_fetch_f32 FETCH_SIZE $PM --scan f32
+pmc pmc_mfma_f32 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" $PM --scan f32
 PM5="bench.py --steps 4 --warmup 1 --no-cpu-baseline --corpus-rows 10000000 --corpus-source random --dtype bf16 --d 256 --nq 4096"
 pmc pmc_fetch_c5 FETCH_SIZE $PM5
 pmc pmc_mfma_c5 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" $PM5

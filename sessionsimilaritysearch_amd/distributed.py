@@ -62,6 +62,7 @@ class HipEngine:
         bad = torch.nonzero(status).flatten()
         if bad.numel():
             self.index.search_exhaustive(q, k, D, I, bad)
+            self.index._note_fallbacks(k, q.shape[0], int(bad.numel()))
         return int(bad.numel())
 
     def merge(self, pack_all, chunk, shards, nq, k, D_out, I_out):

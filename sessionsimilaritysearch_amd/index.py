@@ -21,7 +21,14 @@ from . import _lib
 
 FUSED_DIMS = {"f32": (64, 128, 256), "bf16": (128, 256, 512)}   # row bytes 256 / 512 / 1024
 F16_SCAN_DIMS = (128, 256, 512)                                  # scaled-f16 image: 2 bytes per element
-AUTO_F16_MAX_K = 16     # scan="auto": k up to this uses the one-pass f16 scan, larger k the bf16 split scan
+# scan="auto": the fastest scan whose error bound is still small against the spacing of the scores
+# around rank k (the spacing shrinks as k grows): one-pass f16 up to k = 16, bf16 split up to
+# k = 128, the f32 MFMA beyond.  A search whose fallback share exceeds AUTO_ESCALATE moves that k
+# class one scan up for the following searches (near-duplicate-heavy corpora).
+AUTO_F16_MAX_K = 16
+AUTO_SPLIT_MAX_K = 128
+AUTO_ESCALATE = 0.05
+_LADDER = ("f16", "split", "f32")
 FUSED_MAX_K = 500
 DTYPE_CODE = {"f32": 0, "bf16": 1}                               # include/sss.h: dtype
 _EXHAUSTIVE_WS_BYTES = 1 << 30
@@ -108,8 +115,9 @@ class FlatIndex:
     ``"split"`` keeps each element as a bfloat16 hi/lo pair (same bytes as the f32 row) and scans
     with three bf16 MFMA passes -- error <= ~2^-14 |q||c|;
     ``"f32"`` scans the float32 rows on the f32 MFMA (error ~ d 2^-24) and needs no second image;
-    ``"auto"`` (default) takes "f16" for k <= 16 where the shape allows and "split" otherwise
-    (for large k the k-th scores lie too close together for the f16 bound).  Images are built on
+    ``"auto"`` (default) takes "f16" for k <= 16 where the shape allows, "split" up to k = 128 and
+    "f32" beyond (the scores around rank k lie closer together as k grows), and moves a k class one
+    scan up when a search left more than 5 % of its queries to the fallback.  Images are built on
     first use (``prepare(k)`` does it ahead of time) and extended as rows are added."""
 
     def __init__(self, d: int, metric: str = "ip", device=None, dtype: str = "f32", scan: str | None = None):
@@ -125,6 +133,7 @@ class FlatIndex:
             raise ValueError("scan must be 'auto', 'f16', 'split' or 'f32' for a float32 index")
         self.scan = scan
         self.last_scan = None           # the scan the last fused search used
+        self._auto_level = {}           # scan="auto": k class -> lowest ladder level still allowed
         self.d = int(d)
         self.metric = metric
         self.dtype = dtype
@@ -173,10 +182,20 @@ class FlatIndex:
             return "native" if self.d in FUSED_DIMS[self.dtype] else ""
         want = self.scan
         if want == "auto":
-            want = "f16" if k <= AUTO_F16_MAX_K else "split"
+            level = 0 if k <= AUTO_F16_MAX_K else 1 if k <= AUTO_SPLIT_MAX_K else 2
+            want = _LADDER[max(level, self._auto_level.get(self._k_class(k), 0))]
         if want == "f16" and self.d not in F16_SCAN_DIMS:
             want = "split"
         return want if (want == "f16" or self.d in FUSED_DIMS["f32"]) else ""
+
+    @staticmethod
+    def _k_class(k: int) -> int:
+        return 0 if k <= AUTO_F16_MAX_K else 1 if k <= AUTO_SPLIT_MAX_K else 2
+
+    def _note_fallbacks(self, k: int, nq: int, bad: int):
+        """scan="auto": escalate this k class when too many queries needed the exhaustive path."""
+        if self.scan == "auto" and nq >= 32 and bad > AUTO_ESCALATE * nq and self.last_scan in _LADDER[:-1]:
+            self._auto_level[self._k_class(k)] = _LADDER.index(self.last_scan) + 1
 
     def _grow_image(self, img, done, width, tdtype):
         """The image tensor with room for every row of the store, its first `done` rows kept."""
@@ -369,6 +388,7 @@ class FlatIndex:
             if bad.numel():
                 self.last_fallback_queries = int(bad.numel())
                 self.search_exhaustive(q, k, D, I, bad)
+                self._note_fallbacks(k, nq, int(bad.numel()))
         else:
             self.last_fallback_queries = nq
             self.search_exhaustive(q, k, D, I)

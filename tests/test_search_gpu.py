@@ -490,7 +490,7 @@ def test_auto_scan_picks_by_k_and_shape(cuda):
     c, q = _unit(rng, 9000, 128), _unit(rng, 40, 128)
     idx = FlatIndex(128, "ip", cuda)
     idx.add(c)
-    for k, want in ((10, "f16"), (16, "f16"), (100, "split")):
+    for k, want in ((10, "f16"), (16, "f16"), (100, "split"), (200, "f32")):
         D, I = idx.search(q, k)
         assert idx.last_scan == want
         Dr, Ir = sr.search_exact(q, c, k)
@@ -501,6 +501,25 @@ def test_auto_scan_picks_by_k_and_shape(cuda):
     D, I = idx.search(q64, 10)
     assert idx.last_scan == "split"
     Dr, Ir = sr.search_exact(q64, c64, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_auto_scan_escalates_on_a_near_duplicate_corpus(cuda):
+    """Many near-ties inside the f16 bound: the first search falls back a lot, the next one starts a scan higher."""
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(77)
+    base = _unit(rng, 1500, 128)
+    c = np.repeat(base, 40, axis=0) + (rng.standard_normal((60000, 128)) * 2e-5).astype(np.float32)
+    c = np.ascontiguousarray(c[rng.permutation(60000)]).astype(np.float32)
+    q = _unit(rng, 96, 128)
+    idx = FlatIndex(128, "ip", cuda)
+    idx.add(c)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    D, I = idx.search(q, 10)
+    assert idx.last_scan == "f16" and idx.last_fallback_queries > 5
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    D, I = idx.search(q, 10)
+    assert idx.last_scan == "split"
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
