@@ -30,7 +30,6 @@
 //   * at the end each lane appends its real entries to the query's compact candidate array
 //     (one atomic add per lane) for k_select_* (select.hip).
 #include "scan.h"
-#include <cstdlib>
 
 namespace sss {
 
@@ -76,15 +75,8 @@ __device__ __forceinline__ unsigned min8_sc1(const unsigned* p) {
 
 // NW = waves per workgroup: 8 (two per SIMD, 256 VGPRs each) or, for 1024-byte rows whose resident
 // queries alone take 128 VGPRs, 4 (one per SIMD, 512 VGPRs: no spills; NW * 32 queries per workgroup).
-#ifdef SSS_TIMELINE
-__device__ unsigned long long g_tl[1024 * 8];
-#define TL(slot) do { if (threadIdx.x == 0) g_tl[blockIdx.x * 8 + (slot)] = ((slot) == 0 || (slot) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define TL(slot) do {} while (0)
-#endif
 template <int RB, int TR, int DT, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
-    TL(0); TL(1);
     constexpr int H = TR / 64;                        // 64-row sub-steps per tile
     constexpr int CH = RB / 16;                       // 16-byte chunks per row
     constexpr int NU = RB / 32;                       // k-groups per row (one b128 fragment each)
@@ -399,8 +391,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         };
         walk(q0, 0); walk(q1, 4); walk(q2, 8); walk(q3, 12);     // ascending row order per lane
     };
-
-    TL(2);
     if (ntiles > 0) stage(0, tile_lo);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -472,10 +462,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     };
     const int t_live = boot ? H : 0;            // steps of the bootstrap tile: lane maximum only
     int t = 0;
-    TL(3);
-#ifdef SSS_TIMELINE
-    int n_rare = 0;
-#endif
     while (t < T) {
         bool rare = false;
         for (; t < T; ++t) {                    // ---- hot loop
@@ -484,19 +470,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             if (t % H == H - 1) tile_end(t / H);
         }
         if (!rare) break;
-#ifdef SSS_TIMELINE
-        ++n_rare;
-#endif
         insert_block(acc0, (int)row0_of_step + 4 * h);
         insert_block(acc1, (int)row0_of_step + 32 + 4 * h);
         if (t % H == H - 1) tile_end(t / H);
         ++t;
     }
-
-    TL(4);
-#ifdef SSS_TIMELINE
-    if (threadIdx.x == 0) g_tl[blockIdx.x * 8 + 6] = (unsigned long long)n_rare;
-#endif
     list_insert<KP>(ls, li, pend_s, pend_i);   // no-op for lanes with an empty slot (-inf)
     // ---- append the real entries to the query's compact candidate array
     if (q_glob < nq) {
@@ -512,13 +490,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             if (nreal == KP) atomicMax(A.maxlast + q_glob, (unsigned long long)make_key(ls[KP - 1], li[KP - 1]));
         }
     }
-    TL(5); TL(7);
 }
-#ifdef SSS_TIMELINE
-extern "C" int sss_debug_timeline(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), (size_t)n * 8);
-}
-#endif
 
 // ------------------------------------------------------------------------------ host side
 int current_device() {
@@ -535,11 +507,7 @@ static int pick_splits(long n, int G, int tr) {
     return S;
 }
 
-static int tr256_min_tiles() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("SSS_TR256_MIN_TILES"); v = e ? atoi(e) : 24; }
-    return v;
-}
+constexpr int TR256_MIN_TILES = 24;     // splits at least this many 256-row tiles long use them (256-byte rows)
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -555,7 +523,7 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     if (rb == 512 && (n + (long)S * 128 - 1) / ((long)S * 128) < 48) { tr = 64; S = pick_splits(n, p.G, tr); }
     // 256-byte rows: 256-row tiles (one barrier and one threshold refresh per 256 rows, the next tile's
     // DMA a whole tile ahead) once a split is long enough to amortise the twice-scanned bootstrap tile
-    if (rb == 256 && dtype != DT_F32 && n / ((long)S * 256) >= tr256_min_tiles()) tr = 256;
+    if (rb == 256 && dtype != DT_F32 && n / ((long)S * 256) >= TR256_MIN_TILES) tr = 256;
     p.tile_rows = tr;
     p.S = S;
     p.L = 2 * S;
