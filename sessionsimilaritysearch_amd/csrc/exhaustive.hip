@@ -133,18 +133,26 @@ __global__ __launch_bounds__(256) void k_exact_scores_rows(const void* __restric
 // Correct for any amount of ties (mass duplicates, identical rows).
 constexpr int RS_THREADS = 1024;
 constexpr int RS_MAX_K = 1024;
+// With a compacted input (cs != nullptr and the query's survivors fit `cap`): the select runs over the
+// query's `ctotal` survivors (scores cs, row ids cids, in increasing id order) instead of all n rows.
 __global__ __launch_bounds__(RS_THREADS) void k_topk_radix(const float* __restrict__ scores,
-                                                           const int* __restrict__ qsel, long n, int k,
+                                                           const int* __restrict__ qsel, long n_rows, int k,
                                                            long id_offset, int metric,
-                                                           float* __restrict__ D_out, long* __restrict__ I_out) {
+                                                           float* __restrict__ D_out, long* __restrict__ I_out,
+                                                           const float* __restrict__ cs, const int* __restrict__ cids,
+                                                           const unsigned* __restrict__ ctotal, int cap) {
     __shared__ unsigned hist[256];
     __shared__ unsigned long long keys[RS_MAX_K];
     __shared__ unsigned s_prefix, s_need, s_count, s_wave[RS_THREADS / 64], s_taken;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const float* s = scores + (size_t)f * n;
+    const float* s = scores + (size_t)f * n_rows;
+    const int* ids = nullptr;
+    long n = n_rows;
+    if (cs && ctotal[f] <= (unsigned)cap) { s = cs + (size_t)f * cap; ids = cids + (size_t)f * cap; n = (long)ctotal[f]; }
     const size_t out = (size_t)qsel[f] * k;
     auto key_of = [&](long i) { return f2ord(metric == 0 ? s[i] : -s[i]); };
-    const int kk = (long)k < n ? k : (int)n;            // rows actually returned
+    auto id_of = [&](long i) { return ids ? (unsigned)ids[i] : (unsigned)i; };
+    const int kk = (long)k < n_rows ? k : (int)n_rows;  // rows actually returned (a compacted input holds at least kk)
     int K2 = 64;
     while (K2 < kk) K2 <<= 1;
     for (int i = tid; i < K2; i += RS_THREADS) keys[i] = 0ull;
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_topk_radix(const float* __restri
                 const long i = i0 + (long)u * RS_THREADS;
                 if (i < n && keyv[u] > T) {
                     const unsigned p = atomicAdd(&s_count, 1u);
-                    keys[p] = ((unsigned long long)keyv[u] << 32) | (unsigned)(~(unsigned)i);
+                    keys[p] = ((unsigned long long)keyv[u] << 32) | (unsigned)(~id_of(i));
                 }
             }
         }
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_topk_radix(const float* __restri
         unsigned before = 0;
         for (int w = 0; w < wv; ++w) before += s_wave[w];
         const unsigned rank = s_taken + before + (unsigned)__builtin_popcountll(b & ((1ull << lane) - 1ull));
-        if (hit && rank < want) keys[s_count + rank] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)i);
+        if (hit && rank < want) keys[s_count + rank] = ((unsigned long long)key << 32) | (unsigned)(~id_of(i));
         __syncthreads();
         if (tid == 0) {
             unsigned tot = 0;
@@ -277,7 +285,156 @@ __global__ __launch_bounds__(RS_THREADS) void k_topk_radix(const float* __restri
     }
 }
 
-size_t ip_topk_exhaustive_workspace_bytes(long nsel, long n) { return (size_t)nsel * n * 4 + 256; }
+
+// ---- compaction pre-pass for long rows (n >= CP_MIN_N): the single-workgroup select above is bound by
+// its own load latency (6 sweeps over n).  The kk-th best key of CP_HEAD evenly spread scores is a lower
+// bound T0 of the true kk-th best, so every row of the answer (ties included) has key >= T0; those
+// rows are compacted IN ID ORDER by many workgroups (count per slab, scan, ordered write) and the select
+// then runs over the survivors.  More survivors than CP_CAP (rows sorted ascending, say): the select
+// falls back to the full row -- speed only, never correctness.
+constexpr int CP_HEAD = 65536;
+constexpr int CP_SLAB = 65536;
+constexpr int CP_CAP = 131072;
+constexpr long CP_MIN_N = 262144;
+
+__global__ __launch_bounds__(RS_THREADS) void k_head_threshold(const float* __restrict__ scores, long n, int k, int metric,
+                                                               unsigned* __restrict__ T0) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_need;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const float* s = scores + (size_t)f * n;
+    const long head = n < CP_HEAD ? n : CP_HEAD;         // sample size; rows i * stride: an evenly spread sample
+    const long stride = n / head;                        // (corpora are often ordered -- by session length, by prefix ...)
+    unsigned need = (unsigned)((long)k < head ? k : head), prefix = 0, mask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = tid; i < 256; i += RS_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (long i = tid; i < head; i += RS_THREADS) {
+            const float v = s[i * stride];
+            const unsigned key = f2ord(metric == 0 ? v : -v);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (cum + hist[b] >= need) break;
+                cum += hist[b];
+            }
+            s_prefix = prefix | ((unsigned)b << shift);
+            s_need = need - cum;
+        }
+        __syncthreads();
+        prefix = s_prefix; need = s_need;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    if (tid == 0) T0[f] = prefix;
+}
+
+// grid (slabs, nsel): rows of one slab of one query with key > T0 and with key == T0.  Of the rows EQUAL to
+// T0 only the kk lowest ids can ever be needed (the true kk-th best is >= T0; if it is T0 the answer takes
+// the lowest ids among its ties), so a boundary inside a huge group of identical rows still compacts.
+__global__ __launch_bounds__(256) void k_count_ge(const float* __restrict__ scores, long n, int metric,
+                                                  const unsigned* __restrict__ T0, int nslabs, unsigned* __restrict__ cnt_gt,
+                                                  unsigned* __restrict__ cnt_eq) {
+    __shared__ unsigned s_g[4], s_e[4];
+    const int f = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+    const float* s = scores + (size_t)f * n;
+    const unsigned t0 = T0[f];
+    const long lo = (long)slab * CP_SLAB, hi = lo + CP_SLAB < n ? lo + CP_SLAB : n;
+    unsigned g = 0, e = 0;
+    for (long i = lo + tid; i < hi; i += 256) {
+        const unsigned key = f2ord(metric == 0 ? s[i] : -s[i]);
+        g += key > t0 ? 1u : 0u;
+        e += key == t0 ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e += __shfl_xor(e, o); }
+    if ((tid & 63) == 0) { s_g[tid >> 6] = g; s_e[tid >> 6] = e; }
+    __syncthreads();
+    if (tid == 0) {
+        cnt_gt[(size_t)f * nslabs + slab] = s_g[0] + s_g[1] + s_g[2] + s_g[3];
+        cnt_eq[(size_t)f * nslabs + slab] = s_e[0] + s_e[1] + s_e[2] + s_e[3];
+    }
+}
+
+// one thread block per query: exclusive scans of its slab counts (in place) + the number of rows kept
+__global__ __launch_bounds__(64) void k_scan_slabs(unsigned* __restrict__ cnt_gt, unsigned* __restrict__ cnt_eq, int nslabs,
+                                                   long n, int k, unsigned* __restrict__ total) {
+    const int f = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const unsigned kk = (unsigned)((long)k < n ? k : n);
+    unsigned rg = 0, re = 0;
+    for (int j = 0; j < nslabs; ++j) {
+        const unsigned g = cnt_gt[(size_t)f * nslabs + j], e = cnt_eq[(size_t)f * nslabs + j];
+        cnt_gt[(size_t)f * nslabs + j] = rg;
+        cnt_eq[(size_t)f * nslabs + j] = re;
+        rg += g; re += e;
+    }
+    total[f] = rg + (re < kk ? re : kk);
+}
+
+// grid (slabs, nsel): ordered write of the slab's kept rows (key > T0, or key == T0 among the first kk such
+// rows of the query) at position (#greater before) + min(#equal before, kk): ids ascending.
+__global__ __launch_bounds__(RS_THREADS) void k_compact_ge(const float* __restrict__ scores, long n, int k, int metric,
+                                                           const unsigned* __restrict__ T0, int nslabs,
+                                                           const unsigned* __restrict__ off_gt, const unsigned* __restrict__ off_eq,
+                                                           const unsigned* __restrict__ total, int cap, float* __restrict__ cs,
+                                                           int* __restrict__ cids) {
+    __shared__ unsigned s_wg[RS_THREADS / 64], s_we[RS_THREADS / 64];
+    __shared__ unsigned s_bg, s_be;
+    const int f = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (total[f] > (unsigned)cap) return;                 // does not fit: the select reads the full row
+    const float* s = scores + (size_t)f * n;
+    const unsigned t0 = T0[f];
+    const unsigned kk = (unsigned)((long)k < n ? k : n);
+    const long lo = (long)slab * CP_SLAB, hi = lo + CP_SLAB < n ? lo + CP_SLAB : n;
+    if (tid == 0) { s_bg = off_gt[(size_t)f * nslabs + slab]; s_be = off_eq[(size_t)f * nslabs + slab]; }
+    __syncthreads();
+    for (long base = lo; base < hi; base += RS_THREADS) {
+        const long i = base + tid;
+        float v = 0.f;
+        bool gt = false, eq = false;
+        if (i < hi) {
+            v = s[i];
+            const unsigned key = f2ord(metric == 0 ? v : -v);
+            gt = key > t0; eq = key == t0;
+        }
+        const unsigned long long bg = __builtin_amdgcn_ballot_w64(gt), be = __builtin_amdgcn_ballot_w64(eq);
+        if (lane == 0) { s_wg[wv] = (unsigned)__builtin_popcountll(bg); s_we[wv] = (unsigned)__builtin_popcountll(be); }
+        __syncthreads();
+        unsigned g_before = s_bg, e_before = s_be, g_tot = 0, e_tot = 0;
+        for (int w = 0; w < RS_THREADS / 64; ++w) {
+            const unsigned cg = s_wg[w], ce = s_we[w];
+            if (w < wv) { g_before += cg; e_before += ce; }
+            g_tot += cg; e_tot += ce;
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        g_before += (unsigned)__builtin_popcountll(bg & below);
+        e_before += (unsigned)__builtin_popcountll(be & below);
+        if (gt || (eq && e_before < kk)) {
+            const unsigned pos = g_before + (e_before < kk ? e_before : kk);
+            cs[(size_t)f * cap + pos] = v;
+            cids[(size_t)f * cap + pos] = (int)i;
+        }
+        __syncthreads();
+        if (tid == 0) { s_bg += g_tot; s_be += e_tot; }
+        __syncthreads();
+    }
+}
+
+static size_t compact_bytes(long nsel, long n) {
+    if (n < CP_MIN_N) return 0;
+    const long nslabs = (n + CP_SLAB - 1) / CP_SLAB;
+    return (size_t)nsel * ((size_t)CP_CAP * 8 + (size_t)nslabs * 8 + 8) + 1024;
+}
+
+size_t ip_topk_exhaustive_workspace_bytes(long nsel, long n) {
+    return (((size_t)nsel * n * 4 + 255) & ~(size_t)255) + 256 + compact_bytes(nsel, n);
+}
 
 int ip_topk_exhaustive(const void* q, const int* qsel, long nsel, const void* c, long n, int d,
                        int k, int dtype, long id_offset, int metric, float* D_out, long* I_out, void* ws,
@@ -309,7 +466,27 @@ int ip_topk_exhaustive(const void* q, const int* qsel, long nsel, const void* c,
 #undef SSS_ROWS
     int rc = check_launch("k_exact_scores");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_topk_radix, dim3((unsigned)nsel), dim3(RS_THREADS), 0, st, scores, qsel, n, k, id_offset, metric, D_out, I_out);
+    const float* cs = nullptr; const int* cids = nullptr; const unsigned* ctotal = nullptr;
+    if (n >= CP_MIN_N) {
+        const int nslabs = (int)((n + CP_SLAB - 1) / CP_SLAB);
+        char* p = reinterpret_cast<char*>(ws) + (((size_t)nsel * n * 4 + 255) & ~(size_t)255);
+        float* cs_w = reinterpret_cast<float*>(p);                       p += (size_t)nsel * CP_CAP * 4;
+        int* cids_w = reinterpret_cast<int*>(p);                         p += (size_t)nsel * CP_CAP * 4;
+        unsigned* cnt_gt = reinterpret_cast<unsigned*>(p);               p += (size_t)nsel * nslabs * 4;
+        unsigned* cnt_eq = reinterpret_cast<unsigned*>(p);               p += (size_t)nsel * nslabs * 4;
+        unsigned* T0 = reinterpret_cast<unsigned*>(p);                   p += (size_t)nsel * 4;
+        unsigned* total = reinterpret_cast<unsigned*>(p);
+        hipLaunchKernelGGL(k_head_threshold, dim3((unsigned)nsel), dim3(RS_THREADS), 0, st, scores, n, k, metric, T0);
+        hipLaunchKernelGGL(k_count_ge, dim3((unsigned)nslabs, (unsigned)nsel), dim3(256), 0, st, scores, n, metric, T0, nslabs, cnt_gt, cnt_eq);
+        hipLaunchKernelGGL(k_scan_slabs, dim3((unsigned)nsel), dim3(64), 0, st, cnt_gt, cnt_eq, nslabs, n, k, total);
+        hipLaunchKernelGGL(k_compact_ge, dim3((unsigned)nslabs, (unsigned)nsel), dim3(RS_THREADS), 0, st, scores, n, k, metric, T0, nslabs,
+                           cnt_gt, cnt_eq, total, CP_CAP, cs_w, cids_w);
+        rc = check_launch("k_compact_ge");
+        if (rc) return rc;
+        cs = cs_w; cids = cids_w; ctotal = total;
+    }
+    hipLaunchKernelGGL(k_topk_radix, dim3((unsigned)nsel), dim3(RS_THREADS), 0, st, scores, qsel, n, k, id_offset, metric, D_out, I_out,
+                       cs, cids, ctotal, CP_CAP);
     return check_launch("k_topk_radix");
 }
 
