@@ -1,0 +1,9 @@
+"""Dev helper: quick_search_bench with an alternative build of libsss (scripts/dev/<name>.so)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from sessionsimilaritysearch_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), sys.argv[1])
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import quick_search_bench as qb
+for a in sys.argv[2:]:
+    qb.run(*tuple(int(v) if v.isdigit() else v for v in a.split(",")))
