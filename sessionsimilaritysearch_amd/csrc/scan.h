@@ -25,7 +25,7 @@ constexpr int DT_F16 = 3;
 
 // shift that maps a largest magnitude `amax` into [2^12, 2^13); 0 for an all-zero / non-finite row
 __host__ __device__ inline int f16_shift(float amax) {
-    if (!(amax > 0.f) || !(amax <= 3.0e38f)) return 0;
+    if (!(amax > 0.f) || !(amax <= 3.4028234663852886e38f)) return 0;   // zero, NaN or inf
     int e;
     (void)frexpf(amax, &e);          // amax = m * 2^e, m in [0.5, 1)
     return 13 - e;
