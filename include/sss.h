@@ -212,7 +212,13 @@ int sss_linear_grouped(const sss_linear_problem* problems, int n_problems, int k
  *           yq [nq, >=  h+2]: xs_q | alpha_src(qp) alpha_dst(pq)
  * where u = x (W_ggc W_ih^T) -- GRU input transform applied before the (linear) neighbour sum --
  * and gh = W_hh x + b_hh.  CSR by target, int32; n_self_loop as in sss_gat_aggregate (both GAT
- * directions).  h <= 256. */
+ * directions).  h <= 256.
+ * Table mode (layer 0 of an encoder whose node features are rows of an embedding table): the
+ * transforms of a node depend only on its table row, so the caller transforms the TABLES once
+ * (yp = item_table W^T [n_items, ..], yq = query_table W^T) and passes row_p / row_q (int64 table row of
+ * every node; NULL = node i uses row i): every read of yp / yq / xin_p goes through them and the layer
+ * needs no per-batch transform launch.  x0_p / x0_q (may be NULL): the node's raw feature row (d_x
+ * floats; xin_p resp. xq_table) is also written there -- slice 0 of the node buffers. */
 typedef struct {
     const float* yp; int64_t ld_yp; const float* yq; int64_t ld_yq; int32_t h; int32_t d_x;
     const int32_t* rowptr_qp; const int32_t* col_qp; const int32_t* rowptr_pp; const int32_t* col_pp;
@@ -221,6 +227,9 @@ typedef struct {
     const int32_t* rowptr_pq; const int32_t* col_pq; const float* bias_pq;
     float* out_q; int64_t ld_out_q; int64_t nq;
     int64_t n_self_loop;
+    const int64_t* row_p; const int64_t* row_q;                 /* table mode (NULL: identity) */
+    float* x0_p; int64_t ld_x0_p;                               /* optional copy of the product feature rows */
+    const float* xq_table; int64_t ld_xq; float* x0_q; int64_t ld_x0_q;   /* optional copy of the query feature rows */
 } sss_layer_args;
 int sss_hetero_layer_update(const sss_layer_args* args, void* stream);
 

@@ -108,7 +108,9 @@ class LayerArgs(ctypes.Structure):
                 ("w_pp", c_void_p), ("bias_qp", c_void_p), ("b_ih", c_void_p),
                 ("xin_p", c_void_p), ("ld_xin", c_int64), ("out_p", c_void_p), ("ld_out_p", c_int64), ("np", c_int64),
                 ("rowptr_pq", c_void_p), ("col_pq", c_void_p), ("bias_pq", c_void_p),
-                ("out_q", c_void_p), ("ld_out_q", c_int64), ("nq", c_int64), ("n_self_loop", c_int64)]
+                ("out_q", c_void_p), ("ld_out_q", c_int64), ("nq", c_int64), ("n_self_loop", c_int64),
+                ("row_p", c_void_p), ("row_q", c_void_p), ("x0_p", c_void_p), ("ld_x0_p", c_int64),
+                ("xq_table", c_void_p), ("ld_xq", c_int64), ("x0_q", c_void_p), ("ld_x0_q", c_int64)]
 
 
 def exported_symbols():

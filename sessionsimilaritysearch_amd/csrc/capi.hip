@@ -74,6 +74,9 @@ struct LayerArgs {
     const float* bias_qp; const float* b_ih; const float* xin_p; long ld_xin; int d_x; float* out_p; long ld_outp; long Np;
     const int* rowptr_pq; const int* col_pq; const float* bias_pq; float* out_q; long ld_outq; long Nq;
     long n_self_loop;
+    const long* row_p = nullptr; const long* row_q = nullptr;
+    float* x0_p = nullptr; long ld_x0p = 0;
+    const float* xq_table = nullptr; long ld_xq = 0; float* x0_q = nullptr; long ld_x0q = 0;
 };
 int layer_update(const LayerArgs&, hipStream_t);
 int pool_expand_mean(const float*, const float*, long, const int*, const int*, const int*, const int*, long, long, int, int,
@@ -107,7 +110,7 @@ int graph_fill(const long*, const unsigned char*, const long*, const long*, long
 
 extern "C" {
 
-int sss_version(void) { return 220; }
+int sss_version(void) { return 230; }
 const char* sss_last_error(void) { return sss::g_err; }
 
 int sss_normalize_rows(float* x, int64_t n, int d, int64_t ld, float eps, int rule, void* stream) {
@@ -233,6 +236,8 @@ int sss_hetero_layer_update(const sss_layer_args* a, void* stream) {
     l.bias_qp = a->bias_qp; l.b_ih = a->b_ih; l.xin_p = a->xin_p; l.ld_xin = a->ld_xin; l.out_p = a->out_p;
     l.ld_outp = a->ld_out_p; l.Np = a->np; l.rowptr_pq = a->rowptr_pq; l.col_pq = a->col_pq; l.bias_pq = a->bias_pq;
     l.out_q = a->out_q; l.ld_outq = a->ld_out_q; l.Nq = a->nq; l.n_self_loop = a->n_self_loop;
+    l.row_p = reinterpret_cast<const long*>(a->row_p); l.row_q = reinterpret_cast<const long*>(a->row_q);
+    l.x0_p = a->x0_p; l.ld_x0p = a->ld_x0_p; l.xq_table = a->xq_table; l.ld_xq = a->ld_xq; l.x0_q = a->x0_q; l.ld_x0q = a->ld_x0_q;
     return sss::layer_update(l, ST(stream));
 }
 int sss_pool_expand_mean(const float* lin_p, const float* lin_q, int64_t ld_lin, const int32_t* src_row,

@@ -577,6 +577,11 @@ struct LayerArgs {
     const float* bias_qp; const float* b_ih; const float* xin_p; long ld_xin; int d_x; float* out_p; long ld_outp; long Np;
     const int* rowptr_pq; const int* col_pq; const float* bias_pq; float* out_q; long ld_outq; long Nq;
     long n_self_loop;                  // > 0: PyG bipartite self-loop rewrite on the fly, n = min(Nq, Np)
+    // table mode (layer 0 over embedding-table features): Yp / Yq / xin_p are per TABLE ROW and node i uses
+    // row row_p[i] / row_q[i]; the raw feature rows are copied to x0_p / x0_q (slice 0 of the node buffers)
+    const long* row_p = nullptr; const long* row_q = nullptr;
+    float* x0_p = nullptr; long ld_x0p = 0;
+    const float* xq_table = nullptr; long ld_xq = 0; float* x0_q = nullptr; long ld_x0q = 0;
 };
 
 __device__ __forceinline__ float4 f4_fma(float w, float4 x, float4 a) {
@@ -591,12 +596,14 @@ __device__ __forceinline__ float leaky02(float v) { return v > 0.f ? v : 0.2f * 
 // appended after the target's other edges (what remove_self_loops + add_self_loops + a stable
 // sort by target produce).
 __device__ __forceinline__ float4 gat_row(const float* xs, long ld, const float* a_src_col, float ad, const int* col,
-                                          int e0, int e1, int c4, const float* bias, long skip_i, long self_i) {
+                                          int e0, int e1, int c4, const float* bias, long skip_i, long self_i,
+                                          const long* row_of = nullptr) {
     // one pass (online softmax): a new maximum rescales what has been summed so far, so every
     // edge's index / score / row is loaded exactly once
     float mx = -INFINITY, den = 0.f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto edge = [&](long j) {
+    auto edge = [&](long jn) {
+        const long j = row_of ? row_of[jn] : jn;           // table mode: the source node's table row
         const float v = leaky02(a_src_col[j * ld] + ad);
         const float4 x = *reinterpret_cast<const float4*>(xs + j * ld + c4);
         if (v > mx) {
@@ -627,23 +634,32 @@ __global__ __launch_bounds__(256) void k_layer_update(const LayerArgs A) {
     if (c4 >= h || t >= A.Np + A.Nq) return;
     if (t >= A.Np) {                                            // ---- query target
         const long i = t - A.Np;
-        const float ad = A.Yq[i * A.ldyq + h + 1];
+        const long ri = A.row_q ? A.row_q[i] : i;
+        const float ad = A.Yq[ri * A.ldyq + h + 1];
         const bool lp = i < A.n_self_loop;
         float4 o = gat_row(A.Yp, A.ldyp, A.Yp + 7 * h, ad, A.col_pq, A.rowptr_pq[i], A.rowptr_pq[i + 1], c4, A.bias_pq,
-                           A.n_self_loop > 0 ? i : -1, lp ? i : -1);
+                           A.n_self_loop > 0 ? i : -1, lp ? i : -1, A.row_p);
+        if (A.x0_q) {                                           // raw query features -> slice 0 of the node buffer
+            const float* xq = A.xq_table + ri * A.ld_xq;
+            float* dq = A.x0_q + i * A.ld_x0q;
+            if (c4 + 3 < A.d_x) *reinterpret_cast<float4*>(dq + c4) = *reinterpret_cast<const float4*>(xq + c4);
+            else for (int u = 0; u < 4; ++u) if (c4 + u < A.d_x) dq[c4 + u] = xq[c4 + u];
+        }
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
         *reinterpret_cast<float4*>(A.out_q + i * A.ld_outq + c4) = o;
         return;
     }
     const long i = t;                                           // ---- product target
-    const float* yi = A.Yp + i * A.ldyp;
+    const long ri = A.row_p ? A.row_p[i] : i;
+    const float* yi = A.Yp + ri * A.ldyp;
     const float4 t1 = gat_row(A.Yq, A.ldyq, A.Yq + h, yi[7 * h + 1], A.col_qp, A.rowptr_qp[i], A.rowptr_qp[i + 1], c4, A.bias_qp,
-                              A.n_self_loop > 0 ? i : -1, i < A.n_self_loop ? i : -1);
+                              A.n_self_loop > 0 ? i : -1, i < A.n_self_loop ? i : -1, A.row_q);
     float4 gr = *reinterpret_cast<const float4*>(A.b_ih + c4);
     float4 gz = *reinterpret_cast<const float4*>(A.b_ih + h + c4);
     float4 gn = *reinterpret_cast<const float4*>(A.b_ih + 2 * h + c4);
     for (int e = A.rowptr_pp[i]; e < A.rowptr_pp[i + 1]; ++e) {
-        const float* uj = A.Yp + (long)A.col_pp[e] * A.ldyp + h + c4;
+        const long jn = A.col_pp[e];
+        const float* uj = A.Yp + (A.row_p ? A.row_p[jn] : jn) * A.ldyp + h + c4;
         const float w = A.w_pp ? A.w_pp[e] : 1.f;
         gr = f4_fma(w, *reinterpret_cast<const float4*>(uj), gr);
         gz = f4_fma(w, *reinterpret_cast<const float4*>(uj + h), gz);
@@ -653,12 +669,21 @@ __global__ __launch_bounds__(256) void k_layer_update(const LayerArgs A) {
     const float4 hz = *reinterpret_cast<const float4*>(yi + 5 * h + c4);
     const float4 hn = *reinterpret_cast<const float4*>(yi + 6 * h + c4);
     float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* xi = A.xin_p + i * A.ld_xin;
+    const float* xi = A.xin_p + ri * A.ld_xin;
     if (c4 + 3 < A.d_x) xv = *reinterpret_cast<const float4*>(xi + c4);
     else {
         if (c4 + 0 < A.d_x) xv.x = xi[c4 + 0];
         if (c4 + 1 < A.d_x) xv.y = xi[c4 + 1];
         if (c4 + 2 < A.d_x) xv.z = xi[c4 + 2];
+    }
+    if (A.x0_p) {                                               // raw product features -> slice 0 of the node buffer
+        float* dp = A.x0_p + i * A.ld_x0p;
+        if (c4 + 3 < A.d_x) *reinterpret_cast<float4*>(dp + c4) = xv;
+        else {
+            if (c4 + 0 < A.d_x) dp[c4 + 0] = xv.x;
+            if (c4 + 1 < A.d_x) dp[c4 + 1] = xv.y;
+            if (c4 + 2 < A.d_x) dp[c4 + 2] = xv.z;
+        }
     }
     float4 o;
 #define SSS_GRU1(f)                                                        \
@@ -921,6 +946,10 @@ int layer_update(const LayerArgs& a, hipStream_t st) {
     if (a.h <= 0 || a.h % 4 || a.h > 256 || a.Np < 0 || a.Nq < 0 || a.d_x > a.h || a.ldyp % 4 || a.ldyq % 4 || a.ld_outp % 4 ||
         a.ld_outq % 4 || (a.d_x >= 4 && a.ld_xin % 4) || a.ldyp < 7 * a.h + 2 || a.ldyq < a.h + 2) {
         set_error("layer_update: need h %% 4 == 0, h <= 256, d_x <= h, 16-byte aligned row strides, ldyp >= 7h+2, ldyq >= h+2");
+        return SSS_EINVAL;
+    }
+    if ((a.x0_p && a.ld_x0p % 4) || (a.x0_q && (!a.xq_table || a.ld_xq % 4 || a.ld_x0q % 4))) {
+        set_error("layer_update: x0_p / x0_q need 16-byte aligned row strides, x0_q needs xq_table");
         return SSS_EINVAL;
     }
     const long total = a.Np + a.Nq;

@@ -405,6 +405,32 @@ class SessionEncoder:
                       NP=torch.empty((pb.Np, W), dtype=torch.float32, device=dev), calls={})
         return ws
 
+    # Layer 0 over embedding-table features: a node's transforms depend only on its table row, so the
+    # TABLES are transformed once (same kernel, hence the same bits as transforming the gathered rows) and
+    # the layer kernel reads every node's row through its id -- one launch less per forward.
+    TABLE_MODE_MAX_BYTES = 8 << 30
+
+    def _layer0_tables(self):
+        if self.item_table is None or self.query_table is None:
+            return None
+        if getattr(self, "_tabs", None) is None:
+            h, lw = self.cfg.h, self.layers[0]
+            ni, nqy = self.item_table.shape[0], self.query_table.shape[0]
+            if (ni * (7 * h + ALPHA_PAD) + nqy * (h + ALPHA_PAD)) * 4 > self.TABLE_MODE_MAX_BYTES:
+                self._tabs = ()
+            else:
+                Yp = torch.empty((ni, 7 * h + ALPHA_PAD), dtype=torch.float32, device=self.device)
+                Yq = torch.empty((nqy, h + ALPHA_PAD), dtype=torch.float32, device=self.device)
+                P_ = _lib.LinearProblem
+                mk = lambda x, w, b, y, n, m: P_(x=x.data_ptr(), ldx=x.stride(0), ids=0, table=0, xcopy=0, ld_xcopy=0,
+                                                 w=w.data_ptr(), ldw=w.stride(0), bias=0 if b is None else b.data_ptr(),
+                                                 y=y.data_ptr(), ldy=y.stride(0), n=n, m=m, act=0)
+                arr = (P_ * 2)(mk(self.item_table, lw["w7"], lw["b7"], Yp, ni, 7 * h + 2),
+                               mk(self.query_table, lw["wq"], None, Yq, nqy, h + 2))
+                _lib.check(_lib.lib().sss_linear_grouped(arr, 2, lw["din"], self._st()), "sss_linear_grouped")
+                self._tabs = (Yp, Yq)
+        return self._tabs or None
+
     def _fused_calls(self, pb, ws, gather):
         """ctypes argument blocks of the 7 launches that do not depend on the output tensor,
         built once per (prepared batch, workspace)."""
@@ -424,31 +450,44 @@ class SessionEncoder:
                       y=y.data_ptr(), ldy=y.stride(0), n=n, m=m, act=0)
 
         steps, keep = [], []
+        tabs = self._layer0_tables() if gather else None      # layer-0 transforms of the feature TABLES (weights only)
         for l, lw in enumerate(self.layers):
             off = 0 if l == 0 else cfg.d_in + (l - 1) * h
             din = lw["din"]
             xin_p, xin_q = NP[:, off:off + din], NQ[:, off:off + din]
-            if l == 0 and gather:
+            table0 = l == 0 and tabs is not None
+            if table0:
+                arr = None                                     # no per-batch transform: nodes read their table row's
+            elif l == 0 and gather:
                 pp = prob(None, lw["w7"], lw["b7"], Yp, pb.Np, 7 * h + 2, pb.p_ids, self.item_table, xin_p)
                 pq = prob(None, lw["wq"], None, Yq, pb.Nq, h + 2, pb.q_ids, self.query_table, xin_q)
+                arr = (P_ * 2)(pp, pq)
             else:
                 pp = prob(xin_p, lw["w7"], lw["b7"], Yp, pb.Np, 7 * h + 2)
                 pq = prob(xin_q, lw["wq"], None, Yq, pb.Nq, h + 2)
-            arr = (P_ * 2)(pp, pq)
+                arr = (P_ * 2)(pp, pq)
             out_p = NP[:, cfg.d_in + l * h: cfg.d_in + (l + 1) * h]
             out_q = NQ[:, cfg.d_in + l * h: cfg.d_in + (l + 1) * h]
             rp_qp, c_qp, _ = pb.csr_qp
             rp_pq, c_pq, _ = pb.csr_pq
             rp_pp, c_pp, w_pp = pb.csr_pp
-            la = _lib.LayerArgs(yp=Yp.data_ptr(), ld_yp=Yp.stride(0), yq=Yq.data_ptr(), ld_yq=Yq.stride(0), h=h, d_x=din,
+            yp_l, yq_l = (tabs if table0 else (Yp, Yq))
+            xsrc = self.item_table if table0 else xin_p
+            la = _lib.LayerArgs(yp=yp_l.data_ptr(), ld_yp=yp_l.stride(0), yq=yq_l.data_ptr(), ld_yq=yq_l.stride(0), h=h, d_x=din,
                                 rowptr_qp=rp_qp.data_ptr(), col_qp=c_qp.data_ptr(), rowptr_pp=rp_pp.data_ptr(),
                                 col_pp=c_pp.data_ptr(), w_pp=0 if w_pp is None else w_pp.data_ptr(),
                                 bias_qp=lw["bias_qp"].data_ptr(), b_ih=lw["b_ih"].data_ptr(),
-                                xin_p=xin_p.data_ptr(), ld_xin=NP.stride(0), out_p=out_p.data_ptr(), ld_out_p=NP.stride(0),
+                                xin_p=xsrc.data_ptr(), ld_xin=xsrc.stride(0), out_p=out_p.data_ptr(), ld_out_p=NP.stride(0),
                                 np=pb.Np, rowptr_pq=rp_pq.data_ptr(), col_pq=c_pq.data_ptr(),
                                 bias_pq=lw["bias_pq"].data_ptr(), out_q=out_q.data_ptr(), ld_out_q=NQ.stride(0), nq=pb.Nq,
-                                n_self_loop=pb.n_self_loop)
-            steps.append(("lin", arr, 2, din))
+                                n_self_loop=pb.n_self_loop,
+                                row_p=pb.p_ids.data_ptr() if table0 else 0, row_q=pb.q_ids.data_ptr() if table0 else 0,
+                                x0_p=NP.data_ptr() if table0 else 0, ld_x0_p=NP.stride(0),
+                                xq_table=self.query_table.data_ptr() if table0 else 0,
+                                ld_xq=self.query_table.stride(0) if table0 else 0,
+                                x0_q=NQ.data_ptr() if table0 else 0, ld_x0_q=NQ.stride(0))
+            if arr is not None:
+                steps.append(("lin", arr, 2, din))
             steps.append(("layer", la))
             keep += [arr, la]
         pw, pt = self.pool, self.pool_tab
