@@ -248,7 +248,7 @@ int sss_pool_attention(const float* node, int64_t ld_node, const float* a, int64
                        int64_t n_clicks, int64_t n_graphs, int d, int normalize, float eps, int reduce_sum,
                        float* out, int64_t ld_out, void* stream);
 
-/* The same pooling without materialising the expanded rows (what the fused encoder uses: 7 launches
+/* The same pooling without materialising the expanded rows (what the fused encoder uses: 6-7 launches
  * per forward).  A linear map of an expanded row [tanh(lin[src]) ; tanh(pos_emb[pid])] is a per-node
  * part plus a per-position table entry, so the caller prepares (weights only) tanhpos = tanh(pos_emb)
  * [p, p], a2tab = tanhpos Wn[:, d_lin:]^T + bn [p, d], c2tab = tanhpos Wc[:, d_lin:]^T [p, d], and per

@@ -59,7 +59,7 @@ pb32 = enc.prepare_actions(acts32)
 t = timed(lambda: enc(pb32, l2_normalize=True), n=10)
 h, W, D = 128, 384, 128
 flop = 2.0 * (pb32.Np * (7 * h + 2) * 128 * 2 + pb32.Nq * (h + 2) * 128 * 2 + (pb32.Np + pb32.Nq) * 108 * W + (pb32.Np + pb32.Nq) * 256 * 128)
-out(kernel="fused encoder forward (7 launches)", sessions=32768, ms=round(t * 1e3, 3), sessions_per_s=round(32768 / t),
+out(kernel="fused encoder forward (6 launches, layer 0 in table mode)", sessions=32768, ms=round(t * 1e3, 3), sessions_per_s=round(32768 / t),
     gflop=round(flop / 1e9, 1), TFLOPs=round(flop / t / 1e12, 1), frac_of_f32_mfma=round(flop / t / 157.3e12, 3))
 
 # ---- item vote: 1024 queries x 500 neighbours
