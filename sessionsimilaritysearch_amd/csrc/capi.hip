@@ -5,6 +5,7 @@
 #include "../../include/sss.h"
 #include "sss_common.h"
 #include "scan.h"
+#include "kargs.h"
 
 namespace sss {
 
@@ -62,22 +63,7 @@ int segment_pool(const float*, long, const int*, const int*, long, long, int, co
                  const float*, float*, long, hipStream_t);
 int segment_ptr(const long*, long, long, int*, hipStream_t);
 
-struct LinProb {
-    const float* x; long ldx; const long* ids; const float* table; float* xcopy; long ld_xcopy;
-    const float* w; long ldw; const float* bias; float* y; long ldy; long n; int m; int act; int tiles_m, tile_begin;
-};
-struct LinBatch { LinProb p[4]; int nprob; int K; };
 int linear_grouped(LinBatch&, hipStream_t);
-struct LayerArgs {
-    const float* Yp; long ldyp; const float* Yq; long ldyq; int h;
-    const int* rowptr_qp; const int* col_qp; const int* rowptr_pp; const int* col_pp; const float* w_pp;
-    const float* bias_qp; const float* b_ih; const float* xin_p; long ld_xin; int d_x; float* out_p; long ld_outp; long Np;
-    const int* rowptr_pq; const int* col_pq; const float* bias_pq; float* out_q; long ld_outq; long Nq;
-    long n_self_loop;
-    const long* row_p = nullptr; const long* row_q = nullptr;
-    float* x0_p = nullptr; long ld_x0p = 0;
-    const float* xq_table = nullptr; long ld_xq = 0; float* x0_q = nullptr; long ld_x0q = 0;
-};
 int layer_update(const LayerArgs&, hipStream_t);
 int pool_expand_mean(const float*, const float*, long, const int*, const int*, const int*, const int*, long, long, int, int,
                      const float*, float*, long, float*, long, hipStream_t);
@@ -95,11 +81,6 @@ size_t hamming_exhaustive_workspace_bytes(long nsel, long n);
 int hamming_topk_exhaustive(const unsigned char*, const int*, long, const unsigned char*, long, int, int, long, int*, long*, void*,
                             size_t, hipStream_t);
 int pack_sign_bits(const float*, long, int, long, unsigned char*, int, hipStream_t);
-struct GraphOut {
-    long* q_x; long* q_batch; int* q_pos; long* p_x; long* p_batch; long* p_cnt;
-    int* rowptr_qp; int* col_qp; int* rowptr_pq; int* col_pq; int* rowptr_pp; int* col_pp; float* w_pp;
-    int* src_row; int* pos_id;
-};
 size_t graph_scratch_ints(long S);
 int graph_counts(const long*, const unsigned char*, const long*, long, int*, int*, int*, hipStream_t);
 int graph_fill(const long*, const unsigned char*, const long*, const long*, long, const int*, const GraphOut&, hipStream_t);

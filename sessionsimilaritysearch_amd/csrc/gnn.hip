@@ -13,6 +13,7 @@
 // Dense contractions run on v_mfma_f32_32x32x2_f32 (bit-exact f32 fma chains, the same rate as
 // the f32 VALU peak); everything per-edge / per-node is HBM-bound and moves 16 B per lane.
 #include "sss_common.h"
+#include "kargs.h"
 
 namespace sss {
 
@@ -452,17 +453,6 @@ int segment_ptr(const long* batch, long n, long n_graphs, int* ptr, hipStream_t 
 //   k_pool_attention   attention-weighted per-graph mean (+ optional L2 normalise)
 namespace sss {
 
-struct LinProb {
-    const float* x; long ldx;          // X rows (ignored when ids != nullptr)
-    const long* ids; const float* table;   // gather mode: X[r] = table[ids[r]] (table row stride = K)
-    float* xcopy; long ld_xcopy;       // gather mode: also written here (slice 0 of the node buffer); may be null
-    const float* w; long ldw; const float* bias;
-    float* y; long ldy;
-    long n; int m;
-    int act;                           // epilogue: 0 none, 1 relu, 2 tanh
-    int tiles_m, tile_begin;           // filled by the launcher
-};
-struct LinBatch { LinProb p[4]; int nprob; int K; };
 
 template <int KC>
 __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
@@ -571,18 +561,6 @@ __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
 // Column layout of the node-linear outputs (written by k_linear_grouped, see encoder.py):
 //   Yp [Np, 7h+32]: xs_p | u_r u_z u_n | gh_r gh_z gh_n | a_src(pq) a_dst(qp)
 //   Yq [Nq,  h+32]: xs_q | a_src(qp) a_dst(pq)
-struct LayerArgs {
-    const float* Yp; long ldyp; const float* Yq; long ldyq; int h;
-    const int* rowptr_qp; const int* col_qp; const int* rowptr_pp; const int* col_pp; const float* w_pp;
-    const float* bias_qp; const float* b_ih; const float* xin_p; long ld_xin; int d_x; float* out_p; long ld_outp; long Np;
-    const int* rowptr_pq; const int* col_pq; const float* bias_pq; float* out_q; long ld_outq; long Nq;
-    long n_self_loop;                  // > 0: PyG bipartite self-loop rewrite on the fly, n = min(Nq, Np)
-    // table mode (layer 0 over embedding-table features): Yp / Yq / xin_p are per TABLE ROW and node i uses
-    // row row_p[i] / row_q[i]; the raw feature rows are copied to x0_p / x0_q (slice 0 of the node buffers)
-    const long* row_p = nullptr; const long* row_q = nullptr;
-    float* x0_p = nullptr; long ld_x0p = 0;
-    const float* xq_table = nullptr; long ld_xq = 0; float* x0_q = nullptr; long ld_x0q = 0;
-};
 
 __device__ __forceinline__ float4 f4_fma(float w, float4 x, float4 a) {
     a.x += w * x.x; a.y += w * x.y; a.z += w * x.z; a.w += w * x.w;

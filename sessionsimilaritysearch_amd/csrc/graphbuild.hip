@@ -15,6 +15,7 @@
 // Distinct items keep first-occurrence order (the reference's `list(set(...))` is hash order;
 // documented deviation, sessions.py).
 #include "sss_common.h"
+#include "kargs.h"
 
 namespace sss {
 
@@ -141,14 +142,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(int* __restrict__ data,
     if (i < S) data[(long)blockIdx.y * (S + 1) + i] += bsum[blockIdx.y * nblk + blockIdx.x];
 }
 
-struct GraphOut {
-    long* q_x; long* q_batch; int* q_pos;                         // [Nq]
-    long* p_x; long* p_batch; long* p_cnt;                        // [Np]
-    int* rowptr_qp; int* col_qp;                                  // [Np+1], [E]   targets = products, col = query node
-    int* rowptr_pq; int* col_pq;                                  // [Nq+1], [E]   targets = queries,  col = product node
-    int* rowptr_pp; int* col_pp; float* w_pp;                     // [Np+1], [Epp] targets = products, col = product node
-    int* src_row; int* pos_id;                                    // [n_exp = Xp + Nq]
-};
 
 __global__ __launch_bounds__(256) void k_session_fill(const long* __restrict__ sess_ptr,
                                                       const unsigned char* __restrict__ is_search,

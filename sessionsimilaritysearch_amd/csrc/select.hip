@@ -43,7 +43,12 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
     const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
     const unsigned mh = wave_max_u32(hi);
-    const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+    const unsigned long long own = __builtin_amdgcn_ballot_w64(hi == mh);
+    unsigned ml;
+    if ((own & (own - 1)) == 0)                      // one lane holds the best score (the usual case): its low word
+        ml = (unsigned)__builtin_amdgcn_readlane((int)lo, __builtin_ctzll(own));
+    else
+        ml = wave_max_u32(hi == mh ? lo : 0u);
     return ((unsigned long long)mh << 32) | ml;
 }
 
@@ -53,6 +58,38 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Canonical float64 score of candidate rows, FOUR lanes per row: part p of a row's 16-byte chunks is
+// loaded by lane 4c + p (every load of the row in flight at once: one memory round trip instead of
+// four), and the strictly sequential float64 chain runs part after part, handed from lane to lane --
+// the same additions in the same order as one lane walking the row.  Candidates [c0, c0 + 16) of `sel`.
+__device__ __forceinline__ double dot_chunk(double acc, const char* qrow, int v, f32x4 c, int dtype);
+__device__ __forceinline__ void rescore16(const unsigned long long* sel, double* resc, int c0, int c1, const void* C, int rb,
+                                          const char* qrow, int dtype, int lane) {
+    const int c = c0 + (lane >> 2), p = lane & 3;
+    const int per = rb / 64;                                       // chunks per part: 4 / 8 / 16
+    const unsigned long long key = c < c1 ? sel[c] : 0ull;
+    const bool live = key != 0 && key_id(key) >= 0;
+    f32x4 ch[16];
+    const char* row = reinterpret_cast<const char*>(C) + (size_t)(live ? key_id(key) : 0) * rb + (size_t)p * per * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (live && i < per) ch[i] = *reinterpret_cast<const f32x4*>(row + i * 16);
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (live && p == s) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < per) acc = dot_chunk(acc, qrow, s * per + i, ch[i], dtype);
+        }
+        if (s < 3) {                                               // hand the chain to the next part's lane
+            const double up = __shfl_up(acc, 1);
+            if (p == s + 1) acc = up;
+        }
+    }
+    if (c < c1 && p == 3) resc[c] = live ? acc : 0.0;
 }
 
 // acc += sum over the elements of one 16-byte chunk (4 f32 or 8 bf16), sequential in k
@@ -237,18 +274,7 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     wave_sync();
     // ---- float64 re-score: one lane per candidate walks its corpus row (16-byte loads straight from
     // L2 / HBM, several in flight) sequentially in k -- the canonical order
-    const int nv = rb / 16;
-    for (int c = lane; c < K2; c += 64) {
-        const unsigned long long key = sel[c];
-        double acc = 0.0;
-        if (key != 0 && key_id(key) >= 0) {
-            const char* row = reinterpret_cast<const char*>(A.C) + (size_t)key_id(key) * rb;
-#pragma unroll 8
-            for (int v = 0; v < nv; ++v)
-                acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
-        }
-        resc[c] = acc;
-    }
+    for (int c0 = 0; c0 < K2; c0 += 16) rescore16(sel, resc, c0, K2, A.C, rb, qrow, A.dtype, lane);
     double qn2 = 0.0;
     float q_amax = 0.f;
     for (int kk = lane; kk < A.d; kk += 64) {
@@ -313,15 +339,7 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
         if (K2x == FS_K2) open_end = true;
         wave_sync();
         if (K2x > K2) {
-            for (int c = K2 + lane; c < K2x; c += 64) {
-                const unsigned long long key = sel[c];
-                const char* row = reinterpret_cast<const char*>(A.C) + (size_t)key_id(key) * rb;
-                double acc = 0.0;
-#pragma unroll 8
-                for (int v = 0; v < nv; ++v)
-                    acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
-                resc[c] = acc;
-            }
+            for (int c0 = K2; c0 < K2x; c0 += 16) rescore16(sel, resc, c0, K2x, A.C, rb, qrow, A.dtype, lane);
             if (lane == 0) { *s_nvalid = 0; *s_kth = 0.0; }
             wave_sync();
             rank_and_write<64>(sel, resc, K2x, k, A.id_offset, Dq, Iq, lane, s_nvalid, s_kth);
