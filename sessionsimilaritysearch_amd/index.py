@@ -24,10 +24,12 @@ F16_SCAN_DIMS = (128, 256, 512)                                  # scaled-f16 im
 # scan="auto": the fastest scan whose error bound is still small against the spacing of the scores
 # around rank k (the spacing shrinks as k grows): one-pass f16 up to k = 16, bf16 split up to
 # k = 128, the f32 MFMA beyond.  A search whose fallback share exceeds AUTO_ESCALATE moves that k
-# class one scan up for the following searches (near-duplicate-heavy corpora).
+# class one scan up for the following searches (near-duplicate-heavy corpora): an unproven query
+# costs an O(n d) float64 pass, ~25 us per query per million rows, so half a percent of a batch
+# already outweighs what the faster scan saves.
 AUTO_F16_MAX_K = 16
 AUTO_SPLIT_MAX_K = 128
-AUTO_ESCALATE = 0.05
+AUTO_ESCALATE = 0.005
 _LADDER = ("f16", "split", "f32")
 FUSED_MAX_K = 500
 DTYPE_CODE = {"f32": 0, "bf16": 1}                               # include/sss.h: dtype
@@ -117,7 +119,7 @@ class FlatIndex:
     ``"f32"`` scans the float32 rows on the f32 MFMA (error ~ d 2^-24) and needs no second image;
     ``"auto"`` (default) takes "f16" for k <= 16 where the shape allows, "split" up to k = 128 and
     "f32" beyond (the scores around rank k lie closer together as k grows), and moves a k class one
-    scan up when a search left more than 5 % of its queries to the fallback.  Images are built on
+    scan up when a search left more than 0.5 % of its queries (at least 4) to the fallback.  Images are built on
     first use (``prepare(k)`` does it ahead of time) and extended as rows are added."""
 
     def __init__(self, d: int, metric: str = "ip", device=None, dtype: str = "f32", scan: str | None = None):
@@ -194,7 +196,7 @@ class FlatIndex:
 
     def _note_fallbacks(self, k: int, nq: int, bad: int):
         """scan="auto": escalate this k class when too many queries needed the exhaustive path."""
-        if self.scan == "auto" and nq >= 32 and bad > AUTO_ESCALATE * nq and self.last_scan in _LADDER[:-1]:
+        if self.scan == "auto" and nq >= 32 and bad >= 4 and bad > AUTO_ESCALATE * nq and self.last_scan in _LADDER[:-1]:
             self._auto_level[self._k_class(k)] = _LADDER.index(self.last_scan) + 1
 
     def _grow_image(self, img, done, width, tdtype):
