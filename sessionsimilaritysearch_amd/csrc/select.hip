@@ -68,20 +68,21 @@ __device__ __forceinline__ double dot_chunk(double acc, const char* qrow, int v,
 __device__ __forceinline__ void rescore16(const unsigned long long* sel, double* resc, int c0, int c1, const void* C, int rb,
                                           const char* qrow, int dtype, int lane) {
     const int c = c0 + (lane >> 2), p = lane & 3;
-    const int per = rb / 64;                                       // chunks per part: 4 / 8 / 16
+    const int per = rb / 64;                                       // chunks per part: 4 / 8 / 16 / 32 (rows of 256 .. 2048 bytes)
     const unsigned long long key = c < c1 ? sel[c] : 0ull;
     const bool live = key != 0 && key_id(key) >= 0;
-    f32x4 ch[16];
+    constexpr int MAXP = 32;
+    f32x4 ch[MAXP];
     const char* row = reinterpret_cast<const char*>(C) + (size_t)(live ? key_id(key) : 0) * rb + (size_t)p * per * 16;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < MAXP; ++i)
         if (live && i < per) ch[i] = *reinterpret_cast<const f32x4*>(row + i * 16);
     double acc = 0.0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         if (live && p == s) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
+            for (int i = 0; i < MAXP; ++i)
                 if (i < per) acc = dot_chunk(acc, qrow, s * per + i, ch[i], dtype);
         }
         if (s < 3) {                                               // hand the chain to the next part's lane

@@ -53,6 +53,27 @@ def test_fused_matches_oracle(cuda, nq, n, d, k, scan):
     assert np.abs(D - Dr).max() <= 1e-5
 
 
+@pytest.mark.parametrize("scan_mode,nq,n,d", [
+    ("f16", 100, 20000, 512),      # 1024-byte f16 rows: the 4-wave (one per SIMD) kernel
+    ("f16", 700, 300000, 512),     # ... with the shared threshold and several query groups
+    ("f16", 300, 150000, 256),     # 512-byte f16 rows, 128-row tiles
+    ("f16", 1024, 70000, 128),     # 256-byte rows, short splits (128-row tiles)
+    ("f16", 1024, 900000, 128),    # 256-byte rows, long splits (256-row tiles)
+    ("split", 200, 40000, 256),    # 1024-byte split rows (4-wave kernel)
+    ("split", 513, 400000, 64),    # 256-byte split rows, 256-row tiles
+])
+def test_scan_kernel_variants_match_oracle(cuda, scan_mode, nq, n, d):
+    """Every (row bytes, tile rows, waves) instantiation of the 16-bit scans, at sizes that reach it."""
+    rng = np.random.default_rng(nq + n + d)
+    q, c = _unit(rng, nq, d), _unit(rng, n, d)
+    idx = _index(c, cuda, scan=scan_mode)
+    D, I = idx.search(q, 10)
+    assert idx.last_scan == scan_mode
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    assert idx.last_fallback_queries <= max(2, nq // 100)
+
+
 def test_random_data_is_proven_exact_without_fallback(cuda, scan):
     rng = np.random.default_rng(5)
     q, c = _unit(rng, 512, 128), _unit(rng, 100000, 128)
