@@ -161,6 +161,31 @@ def test_l2_metric(cuda):
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
+def test_exhaustive_path_on_long_rows_l2_ordered_and_tied(cuda):
+    """The exhaustive kernels at n >= 262144 (multi-workgroup compaction before the radix select): the L2
+    metric, a corpus sorted by distance to a query (the sample-based threshold keeps everything: full-row
+    select), and a boundary inside a huge group of identical rows (only the k lowest ids of the ties are kept)."""
+    from sessionsimilaritysearch_amd.index import build_index
+    rng = np.random.default_rng(91)
+    q = rng.standard_normal((6, 64)).astype(np.float32)
+    c = rng.standard_normal((300000, 64)).astype(np.float32)
+    idx = build_index(c, "l2", cuda)
+    D, I = idx.search(q, 10)
+    Dr, Ir = sr.build_index(c, "l2").search(q, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    # ascending similarity to query 0 (ip, d = 1600: no fused shape -> exhaustive for every query)
+    q2 = _unit(rng, 3, 1600)
+    c2 = _unit(rng, 270000, 1600)
+    c2 = np.ascontiguousarray(c2[np.argsort(c2 @ q2[0])])
+    c2[100000:200000] = c2[150000]                     # 100 000 identical rows in the middle
+    q2[1] = c2[150000]                                 # ... which are the best match of query 1: all ties
+    idx2 = build_index(c2, "ip", cuda)
+    D2, I2 = idx2.search(q2, 100)
+    Dr2, Ir2 = sr.search_exact(q2, c2, 100)
+    assert np.array_equal(I2, Ir2) and np.array_equal(D2, Dr2)
+    assert np.array_equal(I2[1], np.arange(100000, 100100))
+
+
 def test_build_index_metrics_and_error(cuda):
     from sessionsimilaritysearch_amd.index import build_index
     rng = np.random.default_rng(10)
