@@ -305,14 +305,14 @@ def main():
             return (time.perf_counter() - t0) / reps, out
         t_embed, e = clock(lambda: gnn_ref.encoder_forward(qb_cpu, weights, cfg.n_layers, self_loops=False).numpy(), 2)
         qn = sr.normalize(e)
-        sample = min(n_total, 131072)                       # bounded sample of the corpus, scaled linearly
+        sample = min(n_total, 1 << 20)                      # the whole 1M default corpus; larger corpora: a 1M-row sample, scaled linearly
         t_search, _ = clock(lambda: sr.search_fp32_blocked(qn, corpus_cpu[:sample], k, block=16384, threads=cores), 2)
         t_full = t_embed + t_search * (n_total / sample)
         log(rank, f"cpu baseline: embed {t_embed:.3f}s, search {t_search:.3f}s on {sample} rows, {cores} threads")
         cpu = {"value": round(nq / t_full, 1), "unit": "queries/s", "cores": cores, "kind": "port",
                "sample": f"{nq} query sessions embedded by the torch-CPU oracle encoder ({t_embed:.3f}s) + blocked "
                          f"float32 SGEMM/top-k (faiss-shaped) over {sample} of {n_total} corpus rows "
-                         f"({t_search:.3f}s, scaled linearly to the full corpus)"}
+                         f"({t_search:.3f}s" + (", scaled linearly to the full corpus)" if sample < n_total else ")")}
 
     mode = index.last_scan          # the scan the timed searches used
     traffic = traffic_detail = None
