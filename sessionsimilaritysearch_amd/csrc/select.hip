@@ -312,16 +312,22 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     int st = decide_status(sel[K2 - 1], maxlast, tau_o, A.J, nvalid, k, *s_kth, B, unscale);
     // ---- second chance for a query whose ONLY problem is the near-tie window (status 4): the pool
     // usually holds more candidates than the K2 the threshold certifies, and it is complete down to
-    // max(threshold, largest tail of a full list).  Take up to FS_K2 of them from that region,
-    // re-score the new ones, rank again; what stays outside is bounded by the first key not taken
-    // (or by the region's floor), which lies further below the k-th result.
+    // max(threshold, largest tail of a full list).  Take candidates from that region -- until the next one
+    // already lies below the k-th result by more than the error window (the k-th result can only rise when
+    // candidates are added), up to FS_K2 in all -- re-score the new ones, rank again; what stays outside
+    // is bounded by the first key not taken (or by the region's floor).
     if (st == 4 && K2 < FS_K2) {                                  // wave-uniform (all lanes computed st)
         const bool has_tau = A.J > 0 && tau_o > ORD_NEG_INF;
         int K2x = K2;
         float edge_score = -INFINITY;
         bool open_end = false;                                    // stopped by the budget: edge = last key taken
+        const double kth0 = *s_kth;                               // lower bound of the final k-th result
         for (; K2x < FS_K2; ++K2x) {
             const unsigned long long w = wave_max_u64(best);
+            if (w != 0 && key_id(w) >= 0 && (double)key_score(w) * unscale + B + 2.4e-7 * fabs(kth0) + 1e-44 < kth0) {
+                edge_score = key_score(w);                        // far enough below: nothing from here on can matter
+                break;
+            }
             const bool inside = w != 0 && key_id(w) >= 0 && w >= maxlast && (!has_tau || f2ord(key_score(w)) >= tau_o);
             if (!inside) {
                 if (w != 0 && key_id(w) >= 0) edge_score = key_score(w);
@@ -345,16 +351,18 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
             wave_sync();
             rank_and_write<64>(sel, resc, K2x, k, A.id_offset, Dq, Iq, lane, s_nvalid, s_kth);
             wave_sync();
-            if (open_end) {
-                edge_score = key_score(sel[K2x - 1]);
-            } else {                                              // everything else lies under the region's floor
-                if (has_tau) edge_score = fmaxf(edge_score, ord2f(tau_o - 1));
-                if (maxlast != 0 && key_id(maxlast) >= 0) edge_score = fmaxf(edge_score, key_score(maxlast));
-            }
-            const double kth = *s_kth;
-            const double reach = (double)edge_score * unscale + B + 2.4e-7 * fabs(kth) + 1e-44;
-            st = (*s_nvalid >= k && reach < kth) ? 0 : 4;
         }
+        // (K2x == K2: the very next candidate already lies far below -- phase 1 only failed because it
+        //  measures the window from the last INCLUDED key)
+        if (open_end) {
+            edge_score = key_score(sel[K2x - 1]);
+        } else {                                                  // everything else lies under the region's floor
+            if (has_tau) edge_score = fmaxf(edge_score, ord2f(tau_o - 1));
+            if (maxlast != 0 && key_id(maxlast) >= 0) edge_score = fmaxf(edge_score, key_score(maxlast));
+        }
+        const double kth = *s_kth;
+        const double reach = (double)edge_score * unscale + B + 2.4e-7 * fabs(kth) + 1e-44;
+        st = (*s_nvalid >= k && reach < kth) ? 0 : 4;
     }
     if (lane == 0) {
         A.status[q] = st;
