@@ -1,9 +1,9 @@
-"""Dev helper: phase stamps of k_select_fast (scripts/dev/libsss_seltl.so, a hand-instrumented build)."""
+"""Dev helper: phase stamps of k_select_fast (scripts/dev/libsss_tl.so: see scripts/dev/README.md)."""
 import sys, os, ctypes, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sessionsimilaritysearch_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsss_seltl.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsss_tl.so")
 import torch
 from sessionsimilaritysearch_amd.index import FlatIndex, normalize_
 nq, n, d, k = 1024, 1000000, 128, 10
