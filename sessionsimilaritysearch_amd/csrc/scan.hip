@@ -1,32 +1,41 @@
-// Query x corpus inner-product scan with fused running top-k (gfx950 / CDNA4), f32 and bf16.
+// Query x corpus inner-product CANDIDATE scan with fused running top-k (gfx950 / CDNA4): f32, bf16,
+// split-bf16 (three passes over an f32 corpus) and scaled f16 (one pass over an f32 corpus).
 //
 // Replaces what the reference asks of faiss at test_amazon_filterd.py:578
 // (`D, I = index.search(normalize(emb), K)`, faiss.IndexFlatIP).
+// The scan's scores never reach the output: select.hip re-scores the candidates in float64 from the
+// stored rows and proves, per query, that nothing outside them could matter (error bound per scan
+// type: select.hip err_bound).
 //
-// k_scan<RB, TR, DT>  -- the dominant kernel (MFMA-bound, DESIGN.md "scoring kernel"); RB = bytes per
-// corpus row (256 / 512 / 1024), TR = rows per LDS tile, DT = element type:
-//   * one workgroup = 8 waves (2 per SIMD) = 256 queries x one contiguous corpus split;
+// k_scan<RB, TR, DT, NW>  -- the dominant kernel (DESIGN.md "scoring kernel"); RB = bytes per scanned
+// corpus row (256 / 512 / 1024), TR = rows per LDS tile (64 / 128 / 256), DT = element type (scan.h),
+// NW = waves per workgroup:
+//   * one workgroup = 8 waves (2 per SIMD) = 256 queries x one contiguous corpus split (1024-byte
+//     rows: 4 waves, one per SIMD, 128 queries);
 //   * each wave keeps its 32 queries resident in RB/8 VGPRs as the B operand of
-//     v_mfma_f32_32x32x2_f32 (DT_F32: an exact k-ordered f32 fma chain) or
-//     v_mfma_f32_32x32x16_bf16 (DT_BF16), so the query tile is read from HBM once;
+//     v_mfma_f32_32x32x2_f32 (DT_F32: an exact k-ordered f32 fma chain), v_mfma_f32_32x32x16_bf16
+//     (DT_BF16; DT_SPLIT: hi*hi + hi*lo + lo*hi of rows stored [hi | lo]) or v_mfma_f32_32x32x16_f16
+//     (DT_F16: f32 queries scaled by their own power of two and rounded in the prologue), so the
+//     query tile is read from HBM once;
 //   * corpus rows stream HBM -> LDS with global_load_lds_dwordx4 (no VGPR staging), double
-//     buffered, 16-byte chunks XOR-swizzled on the SOURCE address so the ds_read_b128 fragment
-//     reads are bank-conflict free.  A 512-byte f32 row (d=128) and a 512-byte bf16 row (d=256)
-//     stage and read identically: lane half h reads chunk 2u+h, which is the k-permuted A operand
-//     of four f32 MFMAs or the natural A operand of one bf16 MFMA;
+//     buffered, one burst per tile, 16-byte chunks XOR-swizzled on the SOURCE address so the
+//     ds_read_b128 fragment reads are bank-conflict free.  Rows of equal BYTES stage and read
+//     identically whatever they hold: lane half h reads chunk 2u+h, which is the k-permuted A operand
+//     of four f32 MFMAs or the natural A operand of one 16-bit MFMA;
 //   * the score matrix is never written: each lane owns one query column of the 32x32
-//     accumulator and keeps a sorted top-KP list (scores + row ids) in registers; the hot path is
-//     one v_max3 tree + one compare per 32x32 block;
-//   * ADMISSION THRESHOLD shared by all workgroups of a query (replaces round 1's sampled
-//     pre-pass kernels): every lane list belongs to one of J classes (J >= K2); slot[q][class]
-//     holds, by atomic max, the best score any list of that class has seen (cert == 1) or the
-//     largest cert-th best of such a list (cert > 1).  Classes partition the corpus rows, so
-//     tau = min over slots is a score that at least J * cert >= K2 distinct rows reach, and a row
-//     scoring below tau can never be among the best K2.  With cert == 1 the first tile of every
-//     split is scanned twice: once max-only to publish (bootstrap), and again at the end with
-//     the lists live, so no row is lost and the expensive "early phase" of a running top-k
-//     (every row beats an empty list) never happens.  Slots only ever hold scores of real rows
-//     and only grow, so a stale read merely admits extra candidates: speed, never correctness.
+//     accumulators and keeps a sorted top-KP list (scores + row ids) in registers.  The scan runs
+//     in 64-row steps: a HOT loop (MFMAs, one v_max3 tree, one compare) that never writes the list
+//     state, left for a RARE insert path only when some lane's step maximum beats its threshold;
+//   * ADMISSION THRESHOLD shared by all workgroups of a query: every lane list belongs to one of J
+//     classes (J >= K2); slot[q][class] holds, by atomic max, the best score any list of that class
+//     has seen (cert == 1) or the largest cert-th best of such a list (cert > 1).  Classes
+//     partition the corpus rows, so tau = min over slots is a score that at least J * cert >= K2
+//     distinct rows reach, and a row scoring below tau can never be among the best K2.  With
+//     cert == 1 the first tile of every split is scanned twice: once max-only to publish
+//     (bootstrap), and again at the end with the lists live, so no row is lost and the expensive
+//     "early phase" of a running top-k (every row beats an empty list) never happens.  Slots only
+//     ever hold scores of real rows and only grow, so a stale read merely admits extra candidates:
+//     speed, never correctness;
 //   * at the end each lane appends its real entries to the query's compact candidate array
 //     (one atomic add per lane) for k_select_* (select.hip).
 #include "scan.h"
