@@ -1,8 +1,9 @@
 // Exhaustive exact search: canonical float64 scores of selected queries against EVERY corpus
-// row, then an exact top-k.  This is the correctness backstop behind k_ip_topk_f32 (queries
+// row, then an exact top-k.  This is the correctness backstop behind the fused scans (queries
 // whose fused result could not be proven exact, tiny corpora, k larger than the fused path,
 // the IndexFlatL2 metric of reference test_amazon_filterd.py:215-217, any d % 4 == 0 such as
-// the reference's D = 1600).  O(n d) scoring + O(n) radix selection per query; DESIGN.md "exactness".
+// the reference's D = 1600).  O(n d) scoring + O(n) radix selection per query (long rows: after a
+// multi-workgroup compaction of the rows that can still matter); DESIGN.md "exactness".
 #include "scan.h"
 
 namespace sss {

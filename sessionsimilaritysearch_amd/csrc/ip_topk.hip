@@ -1,5 +1,6 @@
-// Host orchestration of sss_ip_topk: plan -> k_scan -> k_select_* (two launches; the per-query state
-// words are handed back zeroed by the select kernel, so there is no per-call memset).
+// Host orchestration of sss_ip_topk / sss_ip_topk_f16 / sss_ip_topk_split: plan -> k_scan (over the
+// corpus or its f16 / split image) -> k_select_* (over the stored rows): two launches; the per-query
+// state words are handed back zeroed by the select kernel, so there is no per-call memset.
 // (reference call site: `D, I = index.search(normalize(emb), K)`, test_amazon_filterd.py:578.)
 #include "scan.h"
 

@@ -3,18 +3,21 @@
 // test_amazon_filterd.py:578 (the per-query heap inside IndexFlatIP.search).
 //
 // Input: the compact candidate keys k_scan (scan.hip) appended per query.  Per query:
-//   select the best K2 = k + slack candidates by (float32 score desc, id asc), re-score them in
-//   float64 in the canonical sequential order (== the oracle's score), order by
+//   select the best K2 = k + slack candidates by (scan score desc, id asc), re-score them in
+//   float64 from the stored rows in the canonical sequential order (== the oracle's score), order by
 //   (score desc, id asc), write the first k, and decide
-//   status[q] = 0  proven exact: every row that was NOT re-scored has a float32 score at or
-//                  below the selection edge (it lost to a full list's tail <= edge, or to the
-//                  admission threshold < edge, or it is a candidate ranked below the edge), and
-//                  edge + 2B < k-th re-scored score, B bounding the scan's rounding error;
+//   status[q] = 0  proven exact: every row that was NOT re-scored has a scan score at or below
+//                  the selection edge (it lost to a full list's tail <= edge, or to the admission
+//                  threshold < edge, or it is a candidate ranked below the edge), and
+//                  edge + B + one float32 ulp < k-th re-scored score, B bounding the error of the
+//                  scan that produced the candidates (err_bound; DT_F16 scores are first divided by
+//                  the query's and the corpus' power-of-two scales);
 //            != 0  not proven (bit 0: a full list's tail outranks the edge, bit 1: the admission
 //                  threshold does, bit 2: near-tie window) -> the caller re-runs the query through
 //                  the exhaustive path.
 //   k_select_fast  : one wave per query, K2 <= 32, candidates <= FS_CAP (the common case: the
-//                    shared threshold leaves a few hundred candidates per query)
+//                    shared threshold leaves a few hundred candidates per query); a query that fails
+//                    ONLY the near-tie window gets a second chance with up to 32 candidates
 //   k_select_sort  : one workgroup per query, bitonic sort in LDS, any K2 <= SEL_MAX_K2
 #include "scan.h"
 
