@@ -15,7 +15,7 @@
 //            != 0  not proven (bit 0: a full list's tail outranks the edge, bit 1: the admission
 //                  threshold does, bit 2: near-tie window) -> the caller re-runs the query through
 //                  the exhaustive path.
-//   k_select_fast  : one wave per query, K2 <= 32, candidates <= FS_CAP (the common case: the
+//   k_select_fast  : one wave per query, K2 <= 16, candidates <= FS_CAP (the common case: the
 //                    shared threshold leaves a few hundred candidates per query); a query that fails
 //                    ONLY the near-tie window gets a second chance with up to 32 candidates
 //   k_select_sort  : one workgroup per query, bitonic sort in LDS, any K2 <= SEL_MAX_K2
@@ -24,8 +24,7 @@
 namespace sss {
 
 constexpr int FS_CAP = 2048;       // candidates a wave stages in LDS (more -> unproven)
-constexpr int FS_K2 = 32;          // largest K2 of the wave-per-query kernel (k <= 20); beyond it K2 rounds of
-                                   // wave-wide arg-max lose to the bitonic sort of k_select_sort (measured at K2 = 112)
+constexpr int FS_K2 = 32;          // candidates the wave-per-query kernel can re-score (its second chance widens K2 <= 16 up to this)
 constexpr int SEL_MAX_K2 = 512;
 constexpr int SORT_THREADS = 256;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -492,7 +491,10 @@ __global__ void k_topk_merge(const float* __restrict__ D_in, long d_stride, cons
 int launch_select(const SelectArgs& a, hipStream_t st) {
     const int rb = a.d * elem_bytes(a.dtype);
     const int dev = current_device();
-    if (a.K2 <= FS_K2) {
+    // the wave-per-query kernel serves the K2 <= 16 regime (class maxima + bootstrap: a few hundred
+    // candidates per query); beyond it the lists run without the bootstrap and fill up (thousands of
+    // candidates, more than a wave stages), which is the sort kernel's job
+    if (a.K2 <= KP) {
         const size_t per_wave = (((size_t)FS_CAP * 8 + FS_K2 * 16 + 16 + rb) + 15) & ~(size_t)15;
         const size_t lds = 4 * per_wave;
         static bool done[MAX_DEVICES] = {};
