@@ -16,11 +16,12 @@ for case in range(cases):
     d = int(rng.choice([64, 128, 128, 256, 512, 96]))
     scans = ["auto", "f32", "split", "f16"] if d in (64, 128, 256) else ["auto", "f16"] if d == 512 else ["auto"]
     scan = str(rng.choice(scans))
-    n = int(rng.choice([1, 37, 1000, 4097, 30000, 70001, 150000, 300000]))
+    n = int(rng.choice([1, 37, 1000, 4097, 30000, 70001, 150000, 300000, 600000]))
     if d >= 256:
         n = min(n, 150000)
     nq = int(rng.choice([1, 31, 64, 257, 600, 1024]))
-    k = int(rng.choice([1, 5, 10, 10, 16, 17, 50, 100]))
+    k = int(rng.choice([1, 5, 10, 10, 12, 13, 16, 17, 20, 21, 50, 100, 200, 500]))
+    bf16 = d in (128, 256, 512) and rng.random() < 0.2
     flavour = str(rng.choice(["unit", "unit", "raw", "scaled", "dups", "adds"]))
     c = rng.standard_normal((n, d)).astype(np.float32)
     q = rng.standard_normal((nq, d)).astype(np.float32)
@@ -30,7 +31,11 @@ for case in range(cases):
         c *= np.float32(10.0 ** rng.uniform(-6, 6)); q *= np.float32(10.0 ** rng.uniform(-6, 6))
     if flavour == "dups" and n > 10:
         c[rng.integers(0, n, n // 3)] = c[rng.integers(0, n, n // 3)]
-    idx = FlatIndex(d, "ip", dev, scan=scan)
+    if bf16:                                    # bf16 index: the contract is defined on the rounded vectors
+        c = torch.from_numpy(c).to(torch.bfloat16).float().numpy()
+        q = torch.from_numpy(q).to(torch.bfloat16).float().numpy()
+        scan = "native"
+    idx = FlatIndex(d, "ip", dev, dtype="bf16" if bf16 else "f32", scan=None if bf16 else scan)
     if flavour == "adds" and n > 3:
         cuts = sorted(set(int(v) for v in rng.integers(1, n, 3)))
         for lo, hi in zip([0] + cuts, cuts + [n]):

@@ -536,7 +536,9 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     p.tile_rows = tr;
     p.S = S;
     p.L = 2 * S;
-    p.K2 = k + (k <= 12 ? KP - k : 12);
+    // k <= 16: K2 = 16 (class maxima + bootstrap; the select kernel's second chance widens the candidate set
+    // where the slack K2 - k is too thin for a query); larger k: k + 12
+    p.K2 = k <= KP ? KP : k + 12;
     if ((long)p.L * KP < p.K2) p.K2 = p.L * KP;
     p.total_tiles = (int)((n + tr - 1) / tr);
     p.tiles_per_split = (p.total_tiles + S - 1) / S;
