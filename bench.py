@@ -353,7 +353,7 @@ def main():
                                    + "; query graphs prepared (CSR, on device) before the timed region",
                        "timed_api": api,
                        "corpus_rows": n_total, "rows_per_gpu": hi - lo, "d": d, "k": k, "query_batch": nq,
-                       "parallelism": f"corpus row-sharded x{world}, 1 all-gather + merge" if world > 1 else "single GPU"},
+                       "parallelism": f"corpus row-sharded x{world}; nq/{world} sessions embedded per rank; all-gather of embeddings, all-gather of results + merge" if world > 1 else "single GPU"},
             "recall_at_10": round(recall, 6), "ids_bit_exact": ids_exact, "max_score_err": score_err,
             "recall_queries_checked": nrq, "unproven_queries": unproven,
             "stage_ms": {"embed_normalize": round(embed_ms, 4), "score_topk_merge": round(search_ms, 4),
