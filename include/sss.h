@@ -122,6 +122,16 @@ int sss_ip_topk_exhaustive(const void* q, const int32_t* qsel, int64_t nsel, con
                            float* D_out, int64_t* I_out, void* workspace, size_t workspace_bytes,
                            void* stream);
 
+/* The same (inner-product metric) with a per-query LOWER bound of the k-th best score, lower_bound [nsel]
+ * float32 -- e.g. D_out[q][k-1] of a fused search that returned status != 0: its k-th re-scored candidate
+ * is a real row's canonical score.  A float32 pre-test then skips the float64 chain for every row that
+ * provably scores below the bound (d in {64,128,256} float32 / {128,256} bfloat16; other shapes ignore it).
+ * Results are identical to sss_ip_topk_exhaustive; pass -FLT_MAX where no bound is known. */
+int sss_ip_topk_exhaustive_lb(const void* q, const int32_t* qsel, int64_t nsel, const void* corpus,
+                              int64_t n, int d, int k, int dtype, int64_t id_offset,
+                              const float* lower_bound, float* D_out, int64_t* I_out, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---- multi-GPU: merge per-shard results after the all-gather (no reference equivalent; the
  * reference is single process).  Shard s's [nq, k] block starts at D_in + s * d_shard_stride
  * (floats) / I_in + s * i_shard_stride (int64s); output [nq, k] by (score desc, id asc). */

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "sss_ip_topk_exhaustive": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                        c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                        c_void_p]),
+    "sss_ip_topk_exhaustive_lb": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
+                                          c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sss_topk_merge": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_void_p,
                                c_void_p]),
     "sss_profile_enable": (c_int, [c_int]),

@@ -45,7 +45,7 @@ int topk_merge(const float*, long, const long*, long, int, long, int, float*, lo
 int profile_enable(int);
 int profile_read(double*, int*);
 size_t ip_topk_exhaustive_workspace_bytes(long nsel, long n);
-int ip_topk_exhaustive(const void*, const int*, long, const void*, long, int, int, int, long, int, float*, long*,
+int ip_topk_exhaustive(const void*, const int*, long, const void*, long, int, int, int, long, int, const float*, float*, long*,
                        void*, size_t, hipStream_t);
 int normalize_rows(float*, long, int, long, float, int, hipStream_t);
 int row_norm_max(const void*, long, int, int, float*, hipStream_t);
@@ -91,7 +91,7 @@ int graph_fill(const long*, const unsigned char*, const long*, const long*, long
 
 extern "C" {
 
-int sss_version(void) { return 230; }
+int sss_version(void) { return 240; }
 const char* sss_last_error(void) { return sss::g_err; }
 
 int sss_normalize_rows(float* x, int64_t n, int d, int64_t ld, float eps, int rule, void* stream) {
@@ -150,7 +150,13 @@ size_t sss_ip_topk_exhaustive_workspace_bytes(int64_t nsel, int64_t n) {
 int sss_ip_topk_exhaustive(const void* q, const int32_t* qsel, int64_t nsel, const void* corpus, int64_t n,
                            int d, int k, int dtype, int64_t id_offset, int metric, float* D_out, int64_t* I_out,
                            void* workspace, size_t workspace_bytes, void* stream) {
-    return sss::ip_topk_exhaustive(q, qsel, nsel, corpus, n, d, k, dtype, id_offset, metric, D_out,
+    return sss::ip_topk_exhaustive(q, qsel, nsel, corpus, n, d, k, dtype, id_offset, metric, nullptr, D_out,
+                                   reinterpret_cast<long*>(I_out), workspace, workspace_bytes, ST(stream));
+}
+int sss_ip_topk_exhaustive_lb(const void* q, const int32_t* qsel, int64_t nsel, const void* corpus, int64_t n,
+                              int d, int k, int dtype, int64_t id_offset, const float* lower_bound, float* D_out,
+                              int64_t* I_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return sss::ip_topk_exhaustive(q, qsel, nsel, corpus, n, d, k, dtype, id_offset, 0, lower_bound, D_out,
                                    reinterpret_cast<long*>(I_out), workspace, workspace_bytes, ST(stream));
 }
 int sss_topk_merge(const float* D_in, int64_t d_shard_stride, const int64_t* I_in, int64_t i_shard_stride,

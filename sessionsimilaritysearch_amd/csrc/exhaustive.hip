@@ -66,11 +66,17 @@ __global__ __launch_bounds__(64) void k_exact_scores(const void* __restrict__ Qv
 // ONE corpus row in registers and walks all selected queries (staged through LDS in chunks, read
 // back as broadcasts), so the corpus is read once however many queries need the backstop
 // (k_exact_scores above re-reads it per query).  Same canonical score: sequential float64 sum.
+// lb (optional, one float per selected query): a LOWER bound of the query's k-th best score (the fused
+// path's k-th re-scored candidate).  A cheap float32 pass first bounds every row's score from above
+// (float32 fma chain: error <= d 2^-24 |q||c|); rows that provably stay below lb -- almost all of them --
+// skip the float64 chain and get -FLT_MAX, which the selection ignores.
 template <int D, int DT>
 __global__ __launch_bounds__(256) void k_exact_scores_rows(const void* __restrict__ Qv, const int* __restrict__ qsel, int nsel,
-                                                           const void* __restrict__ Cv, long n, float* __restrict__ scores) {
+                                                           const void* __restrict__ Cv, long n, float* __restrict__ scores,
+                                                           const float* __restrict__ lb) {
     constexpr int QC = 8192 / D;                       // queries per LDS chunk (32 KiB of float32)
     __shared__ __attribute__((aligned(16))) float qs[QC * D];
+    __shared__ float qn[QC];                           // query norms (for the pre-test's error margin)
     constexpr int EB = DT == DT_F32 ? 4 : 2;
     const char* C = reinterpret_cast<const char*>(Cv);
     const char* Q = reinterpret_cast<const char*>(Qv);
@@ -95,6 +101,12 @@ __global__ __launch_bounds__(256) void k_exact_scores_rows(const void* __restric
             }
         }
     }
+    float rnorm = 0.f;
+    if (lb) {
+#pragma unroll
+        for (int kx = 0; kx < D; ++kx) rnorm = fmaf(r[kx], r[kx], rnorm);
+        rnorm = sqrtf(rnorm) * 1.0001f;
+    }
     for (int f0 = 0; f0 < nsel; f0 += QC) {
         const int nf = nsel - f0 < QC ? nsel - f0 : QC;
         __syncthreads();
@@ -105,21 +117,48 @@ __global__ __launch_bounds__(256) void k_exact_scores_rows(const void* __restric
                                  : __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(qrow)[kx] << 16);
         }
         __syncthreads();
+        if (lb) {
+            if (threadIdx.x < nf) {
+                float s2 = 0.f;
+                for (int kx = 0; kx < D; ++kx) s2 = fmaf(qs[threadIdx.x * D + kx], qs[threadIdx.x * D + kx], s2);
+                qn[threadIdx.x] = sqrtf(s2) * 1.0001f;
+            }
+            __syncthreads();
+        }
         for (int f = 0; f < nf; f += 2) {                  // two queries at a time: two independent float64 chains
             const int f1 = f + 1 < nf ? f + 1 : f;
-            double acc0 = 0.0, acc1 = 0.0;
+            bool need0 = true, need1 = true;
+            if (lb) {                                      // float32 upper bounds first
+                float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int v = 0; v < D / 4; ++v) {
-                const f32x4 q4 = *reinterpret_cast<const f32x4*>(qs + f * D + v * 4);     // same address in every lane
-                const f32x4 p4 = *reinterpret_cast<const f32x4*>(qs + f1 * D + v * 4);
-                acc0 += (double)q4.x * (double)r[4 * v];     acc1 += (double)p4.x * (double)r[4 * v];
-                acc0 += (double)q4.y * (double)r[4 * v + 1]; acc1 += (double)p4.y * (double)r[4 * v + 1];
-                acc0 += (double)q4.z * (double)r[4 * v + 2]; acc1 += (double)p4.z * (double)r[4 * v + 2];
-                acc0 += (double)q4.w * (double)r[4 * v + 3]; acc1 += (double)p4.w * (double)r[4 * v + 3];
+                for (int v = 0; v < D / 4; ++v) {
+                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(qs + f * D + v * 4);
+                    const f32x4 p4 = *reinterpret_cast<const f32x4*>(qs + f1 * D + v * 4);
+                    s0 = fmaf(q4.x, r[4 * v], s0);     s1 = fmaf(p4.x, r[4 * v], s1);
+                    s0 = fmaf(q4.y, r[4 * v + 1], s0); s1 = fmaf(p4.y, r[4 * v + 1], s1);
+                    s0 = fmaf(q4.z, r[4 * v + 2], s0); s1 = fmaf(p4.z, r[4 * v + 2], s1);
+                    s0 = fmaf(q4.w, r[4 * v + 3], s0); s1 = fmaf(p4.w, r[4 * v + 3], s1);
+                }
+                const float rel = (float)D * 6.3e-8f * rnorm;                  // d * 2^-24 (+5 %) * |c|
+                const float l0 = lb[f0 + f], l1 = lb[f0 + f1];
+                need0 = !(s0 + rel * qn[f] + 2.4e-7f * fabsf(l0) < l0);        // (NaN anywhere: keep the row)
+                need1 = !(s1 + rel * qn[f1] + 2.4e-7f * fabsf(l1) < l1);
+            }
+            double acc0 = 0.0, acc1 = 0.0;
+            if (need0 || need1) {
+#pragma unroll
+                for (int v = 0; v < D / 4; ++v) {
+                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(qs + f * D + v * 4);     // same address in every lane
+                    const f32x4 p4 = *reinterpret_cast<const f32x4*>(qs + f1 * D + v * 4);
+                    acc0 += (double)q4.x * (double)r[4 * v];     acc1 += (double)p4.x * (double)r[4 * v];
+                    acc0 += (double)q4.y * (double)r[4 * v + 1]; acc1 += (double)p4.y * (double)r[4 * v + 1];
+                    acc0 += (double)q4.z * (double)r[4 * v + 2]; acc1 += (double)p4.z * (double)r[4 * v + 2];
+                    acc0 += (double)q4.w * (double)r[4 * v + 3]; acc1 += (double)p4.w * (double)r[4 * v + 3];
+                }
             }
             if (row < n) {
-                scores[(size_t)(f0 + f) * n + row] = (float)acc0;
-                if (f + 1 < nf) scores[(size_t)(f0 + f + 1) * n + row] = (float)acc1;
+                scores[(size_t)(f0 + f) * n + row] = need0 ? (float)acc0 : -3.4028234663852886e38f;
+                if (f + 1 < nf) scores[(size_t)(f0 + f + 1) * n + row] = need1 ? (float)acc1 : -3.4028234663852886e38f;
             }
         }
     }
@@ -438,8 +477,8 @@ size_t ip_topk_exhaustive_workspace_bytes(long nsel, long n) {
 }
 
 int ip_topk_exhaustive(const void* q, const int* qsel, long nsel, const void* c, long n, int d,
-                       int k, int dtype, long id_offset, int metric, float* D_out, long* I_out, void* ws,
-                       size_t ws_bytes, hipStream_t st) {
+                       int k, int dtype, long id_offset, int metric, const float* lower_bound, float* D_out, long* I_out,
+                       void* ws, size_t ws_bytes, hipStream_t st) {
     if (nsel <= 0 || n <= 0 || k <= 0 || d <= 0 || (dtype != DT_F32 && dtype != DT_BF16) ||
         d % (dtype == DT_F32 ? 4 : 8) || (metric != 0 && metric != 1)) {
         set_error("ip_topk_exhaustive: need nsel, n, k > 0, d %% 4 == 0 (f32) / d %% 8 == 0 (bf16), metric in {0,1}");
@@ -454,7 +493,7 @@ int ip_topk_exhaustive(const void* q, const int* qsel, long nsel, const void* c,
     long gx = (n + EX_ROWS - 1) / EX_ROWS;
     if (gx > 8192) gx = 8192;
     const unsigned rb = (unsigned)((n + 255) / 256);
-#define SSS_ROWS(D_, DT_) hipLaunchKernelGGL((k_exact_scores_rows<D_, DT_>), dim3(rb), dim3(256), 0, st, q, qsel, (int)nsel, c, n, scores)
+#define SSS_ROWS(D_, DT_) hipLaunchKernelGGL((k_exact_scores_rows<D_, DT_>), dim3(rb), dim3(256), 0, st, q, qsel, (int)nsel, c, n, scores, lower_bound)
     if (metric == 0 && dtype == DT_F32 && d == 64) SSS_ROWS(64, DT_F32);
     else if (metric == 0 && dtype == DT_F32 && d == 128) SSS_ROWS(128, DT_F32);
     else if (metric == 0 && dtype == DT_F32 && d == 256) SSS_ROWS(256, DT_F32);

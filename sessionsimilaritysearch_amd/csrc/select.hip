@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     long* Iq = A.I_out + (size_t)q * k;
     const int M = (int)A.cnt[q];
     if (M > FS_CAP) {                                             // adversarial input: let the exhaustive path decide
+        for (int j = lane; j < k; j += 64) { Dq[j] = -3.4028234663852886e38f; Iq[j] = -1; }   // (no k-th score known)
         if (lane == 0) { A.status[q] = 1; if (A.unproven_count) atomicAdd(A.unproven_count, 1); }
         clear_state(A, q, lane, 64);
         return;

@@ -61,7 +61,7 @@ class HipEngine:
     def fix_unproven(self, q, k, D, I, status):
         bad = torch.nonzero(status).flatten()
         if bad.numel():
-            self.index.search_exhaustive(q, k, D, I, bad)
+            self.index.search_exhaustive(q, k, D, I, bad, bounded=True)
             self.index._note_fallbacks(k, q.shape[0], int(bad.numel()))
         return int(bad.numel())
 

@@ -349,8 +349,11 @@ class FlatIndex:
         _lib.check(rc, "sss_ip_topk")
         return D, I, status
 
-    def search_exhaustive(self, q: torch.Tensor, k: int, D: torch.Tensor, I: torch.Tensor, rows=None):
-        """Exhaustive exact path for query rows ``rows`` (all when None); writes into D / I."""
+    def search_exhaustive(self, q: torch.Tensor, k: int, D: torch.Tensor, I: torch.Tensor, rows=None, bounded=False):
+        """Exhaustive exact path for query rows ``rows`` (all when None); writes into D / I.
+        ``bounded``: D[rows, k-1] holds a valid lower bound of each query's k-th best score (what a
+        fused search leaves behind for its unproven queries) -- lets the kernel skip the float64
+        chain for rows that cannot matter."""
         L = _lib.lib()
         n = self.ntotal
         if rows is None:
@@ -362,9 +365,16 @@ class FlatIndex:
             sel = rows[lo:lo + per].contiguous()
             nbytes = L.sss_ip_topk_exhaustive_workspace_bytes(sel.numel(), n)
             ws = self._workspace(nbytes)
-            rc = L.sss_ip_topk_exhaustive(q.data_ptr(), sel.data_ptr(), sel.numel(), self._xb.data_ptr(), n,
-                                          self.d, k, DTYPE_CODE[self.dtype], self.id_offset, metric, D.data_ptr(), I.data_ptr(),
-                                          ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
+            if bounded and metric == 0:
+                lb = D[sel.long(), k - 1].contiguous()
+                rc = L.sss_ip_topk_exhaustive_lb(q.data_ptr(), sel.data_ptr(), sel.numel(), self._xb.data_ptr(), n,
+                                                 self.d, k, DTYPE_CODE[self.dtype], self.id_offset, lb.data_ptr(),
+                                                 D.data_ptr(), I.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 _lib.stream_ptr(self.device))
+            else:
+                rc = L.sss_ip_topk_exhaustive(q.data_ptr(), sel.data_ptr(), sel.numel(), self._xb.data_ptr(), n,
+                                              self.d, k, DTYPE_CODE[self.dtype], self.id_offset, metric, D.data_ptr(),
+                                              I.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
             _lib.check(rc, "sss_ip_topk_exhaustive")
 
     def search_device(self, q: torch.Tensor, k: int):
@@ -389,7 +399,7 @@ class FlatIndex:
             bad = torch.nonzero(status).flatten()
             if bad.numel():
                 self.last_fallback_queries = int(bad.numel())
-                self.search_exhaustive(q, k, D, I, bad)
+                self.search_exhaustive(q, k, D, I, bad, bounded=True)
                 self._note_fallbacks(k, nq, int(bad.numel()))
         else:
             self.last_fallback_queries = nq
