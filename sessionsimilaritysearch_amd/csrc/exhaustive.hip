@@ -63,20 +63,27 @@ __global__ __launch_bounds__(64) void k_exact_scores(const void* __restrict__ Qv
 }
 
 // Fast scorer for the fused kernel's shapes (d = 64 / 128 / 256 elements per row): a lane keeps
-// ONE corpus row in registers and walks all selected queries (staged through LDS in chunks, read
-// back as broadcasts), so the corpus is read once however many queries need the backstop
-// (k_exact_scores above re-reads it per query).  Same canonical score: sequential float64 sum.
+// ONE corpus row in registers and walks all selected queries, so the corpus is read once however
+// many queries need the backstop (k_exact_scores above re-reads it per query).  The query elements are
+// wave-uniform: they come in through the scalar cache (s_load) and enter the FMAs as SGPR operands --
+// no LDS, no barrier.  Same canonical score: sequential float64 sum.
 // lb (optional, one float per selected query): a LOWER bound of the query's k-th best score (the fused
 // path's k-th re-scored candidate).  A cheap float32 pass first bounds every row's score from above
 // (float32 fma chain: error <= d 2^-24 |q||c|); rows that provably stay below lb -- almost all of them --
 // skip the float64 chain and get -FLT_MAX, which the selection ignores.
 template <int D, int DT>
+__device__ __forceinline__ float q_elem(const void* qrow, int kx) {        // element kx of a (wave-uniform) query row
+    if (DT == DT_F32) return reinterpret_cast<const float*>(qrow)[kx];
+    const unsigned w = reinterpret_cast<const unsigned*>(qrow)[kx >> 1];
+    return __builtin_bit_cast(float, (kx & 1) ? (w & 0xFFFF0000u) : (w << 16));
+}
+
+template <int D, int DT>
 __global__ __launch_bounds__(256) void k_exact_scores_rows(const void* __restrict__ Qv, const int* __restrict__ qsel, int nsel,
                                                            const void* __restrict__ Cv, long n, float* __restrict__ scores,
                                                            const float* __restrict__ lb) {
-    constexpr int QC = 8192 / D;                       // queries per LDS chunk (32 KiB of float32)
-    __shared__ __attribute__((aligned(16))) float qs[QC * D];
-    __shared__ float qn[QC];                           // query norms (for the pre-test's error margin)
+    constexpr int QB = 1024;                           // queries whose norms are kept in LDS at a time
+    __shared__ float qn[QB];
     constexpr int EB = DT == DT_F32 ? 4 : 2;
     const char* C = reinterpret_cast<const char*>(Cv);
     const char* Q = reinterpret_cast<const char*>(Qv);
@@ -107,59 +114,34 @@ __global__ __launch_bounds__(256) void k_exact_scores_rows(const void* __restric
         for (int kx = 0; kx < D; ++kx) rnorm = fmaf(r[kx], r[kx], rnorm);
         rnorm = sqrtf(rnorm) * 1.0001f;
     }
-    for (int f0 = 0; f0 < nsel; f0 += QC) {
-        const int nf = nsel - f0 < QC ? nsel - f0 : QC;
-        __syncthreads();
-        for (int i = threadIdx.x; i < nf * D; i += 256) {
-            const int f = i / D, kx = i % D;
-            const char* qrow = Q + (size_t)qsel[f0 + f] * D * EB;
-            qs[i] = DT == DT_F32 ? reinterpret_cast<const float*>(qrow)[kx]
-                                 : __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(qrow)[kx] << 16);
-        }
-        __syncthreads();
-        if (lb) {
-            if (threadIdx.x < nf) {
+    for (int f0 = 0; f0 < nsel; f0 += QB) {
+        const int nf = nsel - f0 < QB ? nsel - f0 : QB;
+        if (lb) {                                          // query norms of this block (for the pre-test's error margin)
+            __syncthreads();
+            for (int t = threadIdx.x; t < nf; t += 256) {
+                const char* qrow = Q + (size_t)qsel[f0 + t] * D * EB;
                 float s2 = 0.f;
-                for (int kx = 0; kx < D; ++kx) s2 = fmaf(qs[threadIdx.x * D + kx], qs[threadIdx.x * D + kx], s2);
-                qn[threadIdx.x] = sqrtf(s2) * 1.0001f;
+                for (int kx = 0; kx < D; ++kx) { const float v = q_elem<D, DT>(qrow, kx); s2 = fmaf(v, v, s2); }
+                qn[t] = sqrtf(s2) * 1.0001f;
             }
             __syncthreads();
         }
-        for (int f = 0; f < nf; f += 2) {                  // two queries at a time: two independent float64 chains
-            const int f1 = f + 1 < nf ? f + 1 : f;
-            bool need0 = true, need1 = true;
-            if (lb) {                                      // float32 upper bounds first
-                float s0 = 0.f, s1 = 0.f;
+        for (int f = 0; f < nf; ++f) {
+            const char* qrow = Q + (size_t)qsel[f0 + f] * D * EB;      // wave-uniform address: scalar loads
+            bool need = true;
+            if (lb) {                                      // float32 upper bound first
+                float s0 = 0.f;
 #pragma unroll
-                for (int v = 0; v < D / 4; ++v) {
-                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(qs + f * D + v * 4);
-                    const f32x4 p4 = *reinterpret_cast<const f32x4*>(qs + f1 * D + v * 4);
-                    s0 = fmaf(q4.x, r[4 * v], s0);     s1 = fmaf(p4.x, r[4 * v], s1);
-                    s0 = fmaf(q4.y, r[4 * v + 1], s0); s1 = fmaf(p4.y, r[4 * v + 1], s1);
-                    s0 = fmaf(q4.z, r[4 * v + 2], s0); s1 = fmaf(p4.z, r[4 * v + 2], s1);
-                    s0 = fmaf(q4.w, r[4 * v + 3], s0); s1 = fmaf(p4.w, r[4 * v + 3], s1);
-                }
-                const float rel = (float)D * 6.3e-8f * rnorm;                  // d * 2^-24 (+5 %) * |c|
-                const float l0 = lb[f0 + f], l1 = lb[f0 + f1];
-                need0 = !(s0 + rel * qn[f] + 2.4e-7f * fabsf(l0) < l0);        // (NaN anywhere: keep the row)
-                need1 = !(s1 + rel * qn[f1] + 2.4e-7f * fabsf(l1) < l1);
+                for (int kx = 0; kx < D; ++kx) s0 = fmaf(q_elem<D, DT>(qrow, kx), r[kx], s0);
+                const float l0 = lb[f0 + f];
+                need = !(s0 + (float)D * 6.3e-8f * rnorm * qn[f] + 2.4e-7f * fabsf(l0) < l0);   // (NaN anywhere: keep the row)
             }
-            double acc0 = 0.0, acc1 = 0.0;
-            if (need0 || need1) {
+            double acc = 0.0;
+            if (need) {
 #pragma unroll
-                for (int v = 0; v < D / 4; ++v) {
-                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(qs + f * D + v * 4);     // same address in every lane
-                    const f32x4 p4 = *reinterpret_cast<const f32x4*>(qs + f1 * D + v * 4);
-                    acc0 += (double)q4.x * (double)r[4 * v];     acc1 += (double)p4.x * (double)r[4 * v];
-                    acc0 += (double)q4.y * (double)r[4 * v + 1]; acc1 += (double)p4.y * (double)r[4 * v + 1];
-                    acc0 += (double)q4.z * (double)r[4 * v + 2]; acc1 += (double)p4.z * (double)r[4 * v + 2];
-                    acc0 += (double)q4.w * (double)r[4 * v + 3]; acc1 += (double)p4.w * (double)r[4 * v + 3];
-                }
+                for (int kx = 0; kx < D; ++kx) acc += (double)q_elem<D, DT>(qrow, kx) * (double)r[kx];
             }
-            if (row < n) {
-                scores[(size_t)(f0 + f) * n + row] = need0 ? (float)acc0 : -3.4028234663852886e38f;
-                if (f + 1 < nf) scores[(size_t)(f0 + f + 1) * n + row] = need1 ? (float)acc1 : -3.4028234663852886e38f;
-            }
+            if (row < n) scores[(size_t)(f0 + f) * n + row] = need ? (float)acc : -3.4028234663852886e38f;
         }
     }
 }
