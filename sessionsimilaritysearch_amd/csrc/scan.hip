@@ -412,9 +412,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     // ~70 v_mov per step on the hot path.)
     const int T = niter * H;
     long row0_of_step = 0;                      // first corpus row of the current step
+    // The threshold moves fast at first and then ever more slowly, and a stale one only admits extra
+    // candidates: the 16-bit scans (whose tiles take a few microseconds) refresh it every tile for the first
+    // 8 tiles and then every 512 rows -- measured 4 % on the f16 scan; the f32 scan (15 us per tile) keeps
+    // refreshing every tile.
+    constexpr int TAU_EVERY = DT == DT_F32 ? 1 : (TR >= 512 ? 1 : 512 / TR);
+    auto refresh_at = [&](int i) { return TAU_EVERY == 1 || i <= 8 || (i % TAU_EVERY) == 0; };
     auto tile_top = [&](int i) {                // threshold refresh at the start of tile iteration i > 0
         if (!use_tau || i == 0) return;
         if (J == 16) {
+            if (!refresh_at(i)) return;
             tau_fetch();                        // lands under this tile's MFMAs
         } else {
             // J > 16 (k > 116): synchronous loads, rarely, staggered between the two waves of a
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         const bool pre = boot && i == 0;
         if (pre) publish();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile landed
-        if (use_tau && J == 16 && i > 0) set_tau(tau_read());   // ... and so did its slots (own region: no barrier needed)
+        if (use_tau && J == 16 && i > 0 && refresh_at(i)) set_tau(tau_read());   // ... and so did its slots (own region: no barrier needed)
         __syncthreads();                                   // ... everyone's did, and this buffer is free
         if (pre) {
             // Wait (bounded) until every class of this wave's queries has published its bootstrap
