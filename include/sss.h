@@ -111,6 +111,24 @@ int sss_ip_topk_f16(const float* q, int64_t nq, const float* corpus, const uint1
                     float* D_out, int64_t* I_out, int32_t* status, int32_t* unproven_count, void* state,
                     size_t state_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Threshold rung: resolves queries a fused search (sss_ip_topk / _split / _f16) left with status != 0 at
+ * matrix-core speed, before the exhaustive kernels are needed.  qsel [nsel] int32 = those query rows.  Row
+ * qsel[i] of D_out still holds the fused search's k-th re-scored candidate in column k-1 -- a valid LOWER BOUND
+ * of the true k-th score; one more scan of `scan_image` for just these queries keeps EVERY row whose scan score
+ * lies above (bound - scan error bound - one float32 ulp) and re-scores them all canonically (float64, from
+ * `corpus`): exact for near ties and for exact ties (duplicate rows) alike.  Resolved queries get their rows of
+ * D_out / I_out rewritten and status 0; a query with more than 8192 such rows (or NaNs) keeps its status and goes
+ * to sss_ip_topk_exhaustive.  scan: 0 / 1 = the corpus itself (f32 / bf16 index: pass scan_image = corpus),
+ * 2 = the [hi | lo] bf16 image (sss_split_bf16), 3 = the scaled float16 image (corpus_shift / corpus_resid_norm
+ * as for sss_ip_topk_f16; ignored otherwise).  Serves the same result contract as the reference's
+ * `index.search` (test_amazon_filterd.py:578).  workspace (256-byte aligned):
+ * sss_ip_topk_threshold_workspace_bytes(nsel, n, d, scan). */
+size_t sss_ip_topk_threshold_workspace_bytes(int64_t nsel, int64_t n, int d, int scan);
+int sss_ip_topk_threshold(const void* q, const int32_t* qsel, int64_t nsel, const void* corpus, int dtype,
+                          const void* scan_image, int scan, int corpus_shift, float corpus_resid_norm, int64_t n,
+                          int d, int k, int64_t id_offset, float corpus_max_norm, float* D_out, int64_t* I_out,
+                          int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Exhaustive exact search for a (small) set of queries: qsel [nsel] int32 are the query rows of
  * q to process; results are written to rows qsel[i] of D_out / I_out.  Any n, any d % 4 == 0
  * (dtype 0) or d % 8 == 0 (dtype 1), k <= 1024.  metric: 0 = inner product, 1 = squared L2
@@ -210,7 +228,10 @@ typedef struct {
     const int64_t* ids; const float* table; float* xcopy; int64_t ld_xcopy;
     const float* w; int64_t ldw; const float* bias;
     float* y; int64_t ldy;
-    int64_t n; int32_t m; int32_t act;      /* epilogue activation: 0 none, 1 relu, 2 tanh */
+    int64_t n; int32_t m; int32_t act;      /* epilogue activation: 0 none, 1 relu, 2 tanh, 3 sign, 4 tanh(tanh(.)) */
+    const float* post_scale;                /* optional [m] (both or neither): after the activation, per output   */
+    const float* post_shift;                /* column v = relu(v * post_scale + post_shift) -- BatchNorm1d in eval */
+                                            /* mode + the relu the reference MLP applies to it (model/model.py:63-65) */
 } sss_linear_problem;
 int sss_linear_grouped(const sss_linear_problem* problems, int n_problems, int k, void* stream);
 
@@ -322,9 +343,11 @@ int sss_graph_fill(const int64_t* sess_ptr, const uint8_t* is_search, const int6
  * sss_hamming_topk: q [nq, nbytes], codes [n, nbytes] uint8, nbytes in {16, 32, 64}; D_out [nq, k]
  *   int32 Hamming distances ascending, I_out [nq, k] int64 ids ordered by (distance asc, id asc),
  *   -1 / INT_MAX padded; status 0 = proven exact, 1 = re-run through the exhaustive entry point.
- *   k <= 16 * splits (typically 1024); returns -1 for larger k (use the exhaustive entry point). */
+ *   k <= sss_hamming_topk_capacity(nq, n) (16 * splits, typically 1024); returns -1 for larger k (use
+ *   the exhaustive entry point). */
 int sss_pack_sign_bits(const float* x, int64_t n, int c, int64_t ldx, uint8_t* out, int nbytes, void* stream);
 size_t sss_hamming_topk_workspace_bytes(int64_t nq, int64_t n);
+int sss_hamming_topk_capacity(int64_t nq, int64_t n);
 int sss_hamming_topk(const uint8_t* q, int64_t nq, const uint8_t* codes, int64_t n, int nbytes, int k,
                      int64_t id_offset, int32_t* D_out, int64_t* I_out, int32_t* status, void* workspace,
                      size_t workspace_bytes, void* stream);

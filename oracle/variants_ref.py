@@ -77,3 +77,19 @@ def mlp(x, w, n_hidden_layers, last_act=True, jump=False):
     last = n_hidden_layers + 1
     y = F.linear(x, w[f"layers.{last}.w"], w[f"layers.{last}.b"])
     return torch.tanh(y) if last_act else y
+
+
+def binarize_head(x, w, mlp_w=None, n_hidden_layers=0, mlp_last_act=True, jump=False, pre_sign=False):
+    """``BinarizeHead.forward`` in eval mode, statement by statement (model/model.py:117-135): ``lin1(x)`` without an
+    mlp, else ``lin1(tanh(mlp(x)))`` (``jump``: ``lin1(cat([tanh(mlp(x)), x]))``), then
+    ``(sign(out) - tanh(out)) + tanh(out)`` -- the reference's straight-through expression, kept as written."""
+    if mlp_w is None:
+        out = F.linear(x, w["lin1.w"], w["lin1.b"])
+    else:
+        out = torch.tanh(mlp(x, mlp_w, n_hidden_layers, mlp_last_act, False))
+        if jump:
+            out = torch.cat([out, x], dim=1)
+        out = F.linear(out, w["lin1.w"], w["lin1.b"])
+    if pre_sign:
+        return out
+    return (torch.sign(out) - torch.tanh(out)) + torch.tanh(out)

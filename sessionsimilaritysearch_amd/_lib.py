@@ -39,6 +39,10 @@ _SIGNATURES = {
     "sss_ip_topk_f16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_float, c_int64, c_int, c_int, c_int64, c_float,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                                 c_void_p]),
+    "sss_ip_topk_threshold_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "sss_ip_topk_threshold": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_int64,
+                                      c_int, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                      c_void_p]),
     "sss_ip_topk_exhaustive_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sss_ip_topk_exhaustive": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                        c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
@@ -65,6 +69,7 @@ _SIGNATURES = {
     "sss_segment_ptr": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "sss_pack_sign_bits": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p]),
     "sss_hamming_topk_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sss_hamming_topk_capacity": (c_int, [c_int64, c_int64]),
     "sss_hamming_topk": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
     "sss_hamming_topk_exhaustive_workspace_bytes": (c_size_t, [c_int64, c_int64]),
@@ -94,7 +99,7 @@ class LinearProblem(ctypes.Structure):
     """``sss_linear_problem`` of include/sss.h."""
     _fields_ = [("x", c_void_p), ("ldx", c_int64), ("ids", c_void_p), ("table", c_void_p), ("xcopy", c_void_p),
                 ("ld_xcopy", c_int64), ("w", c_void_p), ("ldw", c_int64), ("bias", c_void_p), ("y", c_void_p),
-                ("ldy", c_int64), ("n", c_int64), ("m", c_int32), ("act", c_int32)]
+                ("ldy", c_int64), ("n", c_int64), ("m", c_int32), ("act", c_int32), ("post_scale", c_void_p), ("post_shift", c_void_p)]
 
 
 class GraphOut(ctypes.Structure):

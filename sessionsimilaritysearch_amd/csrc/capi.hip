@@ -39,6 +39,9 @@ int ip_topk_f16(const float*, long, const float*, const void*, int, float, long,
                 void*, size_t, void*, size_t, hipStream_t);
 int f16_resid_max(const float*, const unsigned short*, long, int, int, float*, hipStream_t);
 size_t ip_topk_scan_workspace_bytes(long, long, int, int, int);
+size_t ip_topk_threshold_workspace_bytes(long, long, int, int);
+int ip_topk_threshold(const void*, const int*, long, const void*, int, const void*, int, int, float, long, int, int, long, float,
+                      float*, long*, int*, void*, size_t, hipStream_t);
 int abs_max(const float*, long, float*, hipStream_t);
 int scale_f16(const float*, long, int, unsigned short*, hipStream_t);
 int topk_merge(const float*, long, const long*, long, int, long, int, float*, long*, hipStream_t);
@@ -76,6 +79,7 @@ int segment_reduce(const float*, long, const float*, const int*, long, int, int,
 int attention_dot_pool(const float*, long, const int*, long, int, float*, long, hipStream_t);
 int item_vote(const float*, const long*, long, int, const long*, const int*, long, long, int, long*, double*, int*, hipStream_t);
 size_t hamming_workspace_bytes(long nq, long n);
+int hamming_capacity(long nq, long n);
 int hamming_topk(const unsigned char*, long, const unsigned char*, long, int, int, long, int*, long*, int*, void*, size_t, hipStream_t);
 size_t hamming_exhaustive_workspace_bytes(long nsel, long n);
 int hamming_topk_exhaustive(const unsigned char*, const int*, long, const unsigned char*, long, int, int, long, int*, long*, void*,
@@ -144,6 +148,17 @@ int sss_ip_topk_f16(const float* q, int64_t nq, const float* corpus, const uint1
                             reinterpret_cast<long*>(I_out), status, unproven_count, state, state_bytes, workspace,
                             workspace_bytes, ST(stream));
 }
+size_t sss_ip_topk_threshold_workspace_bytes(int64_t nsel, int64_t n, int d, int scan) {
+    return sss::ip_topk_threshold_workspace_bytes(nsel, n, d, scan);
+}
+int sss_ip_topk_threshold(const void* q, const int32_t* qsel, int64_t nsel, const void* corpus, int dtype, const void* scan_image,
+                          int scan, int corpus_shift, float corpus_resid_norm, int64_t n, int d, int k, int64_t id_offset,
+                          float corpus_max_norm, float* D_out, int64_t* I_out, int32_t* status, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    return sss::ip_topk_threshold(q, qsel, nsel, corpus, dtype, scan_image, scan, corpus_shift, corpus_resid_norm, n, d, k,
+                                  id_offset, corpus_max_norm, D_out, reinterpret_cast<long*>(I_out), status, workspace,
+                                  workspace_bytes, ST(stream));
+}
 size_t sss_ip_topk_exhaustive_workspace_bytes(int64_t nsel, int64_t n) {
     return sss::ip_topk_exhaustive_workspace_bytes(nsel, n);
 }
@@ -211,7 +226,11 @@ int sss_linear_grouped(const sss_linear_problem* problems, int n_problems, int k
         sss::LinProb& p = b.p[i];
         p.x = s.x; p.ldx = s.ldx; p.ids = reinterpret_cast<const long*>(s.ids); p.table = s.table; p.xcopy = s.xcopy;
         p.ld_xcopy = s.ld_xcopy; p.w = s.w; p.ldw = s.ldw; p.bias = s.bias; p.y = s.y; p.ldy = s.ldy; p.n = s.n; p.m = s.m;
-        p.act = s.act; p.tiles_m = 0; p.tile_begin = 0;
+        p.act = s.act; p.post_scale = s.post_scale; p.post_shift = s.post_shift; p.tiles_m = 0; p.tile_begin = 0;
+        if (s.act < 0 || s.act > 4 || (s.post_scale == nullptr) != (s.post_shift == nullptr)) {
+            sss::set_error("linear_grouped: problem %d: act must be 0..4, post_scale / post_shift come together", i);
+            return SSS_EINVAL;
+        }
     }
     return sss::linear_grouped(b, ST(stream));
 }
@@ -263,6 +282,7 @@ int sss_pack_sign_bits(const float* x, int64_t n, int c, int64_t ldx, uint8_t* o
     return sss::pack_sign_bits(x, n, c, ldx, out, nbytes, ST(stream));
 }
 size_t sss_hamming_topk_workspace_bytes(int64_t nq, int64_t n) { return sss::hamming_workspace_bytes(nq, n); }
+int sss_hamming_topk_capacity(int64_t nq, int64_t n) { return sss::hamming_capacity(nq, n); }
 int sss_hamming_topk(const uint8_t* q, int64_t nq, const uint8_t* codes, int64_t n, int nbytes, int k, int64_t id_offset,
                      int32_t* D_out, int64_t* I_out, int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
     return sss::hamming_topk(q, nq, codes, n, nbytes, k, id_offset, D_out, reinterpret_cast<long*>(I_out), status, workspace,

@@ -344,12 +344,13 @@ int linear_f32(const float* X, long ldx, const float* W, long ldw, const float* 
     if (N == 0) return SSS_OK;
     dim3 grid((unsigned)((N + LT - 1) / LT), (unsigned)((M + LT - 1) / LT));
     const int lds = 2 * LT * 128 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!attr_done[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_f32<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_f32<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
+        attr_done[dev] = true;
     }
     if (K % 128 == 0)
         hipLaunchKernelGGL(k_linear_f32<128>, grid, dim3(256), lds, st, X, ldx, W, ldw, bias, Y, ldy, N, M, K);
@@ -472,10 +473,11 @@ __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
     float* xcopy = B.p[0].xcopy; long ldc = B.p[0].ld_xcopy; const float* W = B.p[0].w; long ldw = B.p[0].ldw;
     const float* bias = B.p[0].bias; float* Y = B.p[0].y; long ldy = B.p[0].ldy; long N = B.p[0].n; int M = B.p[0].m;
     int tiles_m = B.p[0].tiles_m, tile_begin = B.p[0].tile_begin, act = B.p[0].act;
+    const float* post_s = B.p[0].post_scale; const float* post_t = B.p[0].post_shift;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
         if (pi == i) {
-            act = B.p[i].act;
+            act = B.p[i].act; post_s = B.p[i].post_scale; post_t = B.p[i].post_shift;
             X = B.p[i].x; ldx = B.p[i].ldx; ids = B.p[i].ids; table = B.p[i].table; xcopy = B.p[i].xcopy; ldc = B.p[i].ld_xcopy;
             W = B.p[i].w; ldw = B.p[i].ldw; bias = B.p[i].bias; Y = B.p[i].y; ldy = B.p[i].ldy; N = B.p[i].n; M = B.p[i].m;
             tiles_m = B.p[i].tiles_m; tile_begin = B.p[i].tile_begin;
@@ -537,12 +539,16 @@ __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
     const int col = col0 + wc * 32 + r;
     if (col < M) {
         const float bv = bias ? bias[col] : 0.f;
+        const float ps = post_s ? post_s[col] : 1.f, pt = post_s ? post_t[col] : 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const long row = row0 + wr * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
             float v = acc[j] + bv;
             if (act == 1) v = fmaxf(v, 0.f);
             else if (act == 2) v = tanhf(v);
+            else if (act == 3) v = v > 0.f ? 1.f : v < 0.f ? -1.f : v;     // torch.sign (0 and NaN pass through)
+            else if (act == 4) v = tanhf(tanhf(v));
+            if (post_s) v = fmaxf(v * ps + pt, 0.f);                        // two roundings, as bn(x) in eval mode then relu
             if (row < N) Y[row * ldy + col] = v;
         }
     }

@@ -237,6 +237,7 @@ static int hsplits(long nq, long n) {
     return S < 1 ? 1 : S;
 }
 size_t hamming_workspace_bytes(long nq, long n) { return (size_t)nq * hsplits(nq, n) * HK * 8 + 256; }
+int hamming_capacity(long nq, long n) { return (nq <= 0 || n <= 0) ? 0 : hsplits(nq, n) * HK; }
 
 template <int NW>
 static void launch_hscan(const unsigned* q, int nq, const unsigned* c, int n, int S, unsigned long long* cand, hipStream_t st) {

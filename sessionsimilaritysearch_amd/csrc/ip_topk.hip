@@ -115,6 +115,55 @@ static int ip_topk_impl(const void* q, long nq, const void* c_scan, int scan_dty
     return rc;
 }
 
+// Threshold rung for the queries `qsel` a fused search left unproven (select.hip: THRESHOLD RUNG).
+// Workspace: thr f32 [nsel] | cnt u32 [nsel] | (256-byte aligned) cand u64 [nsel][cap].
+constexpr int THR_CAP = 8192;       // rows kept per query (64 KB of keys in LDS for the sort)
+static size_t thr_head_bytes(long nsel) { return ((size_t)nsel * 8 + 255) & ~(size_t)255; }
+
+size_t ip_topk_threshold_workspace_bytes(long nsel, long n, int d, int scan_dtype) {
+    if (nsel <= 0 || n <= 0 || !fused_shape_ok(d, scan_dtype)) return 0;
+    return thr_head_bytes(nsel) + make_thr_plan(nsel, n, d, scan_dtype, THR_CAP).total_bytes;
+}
+
+int ip_topk_threshold(const void* q, const int* qsel, long nsel, const void* c_exact, int exact_dtype, const void* c_scan,
+                      int scan_dtype, int corpus_shift, float corpus_resid, long n, int d, int k, long id_offset,
+                      float corpus_max_norm, float* D_out, long* I_out, int* status, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (nsel <= 0 || n <= 0 || k <= 0 || !qsel) { set_error("ip_topk_threshold: nsel, n, k must be positive"); return SSS_EINVAL; }
+    if (exact_dtype != DT_F32 && exact_dtype != DT_BF16) { set_error("ip_topk_threshold: dtype must be 0 (f32) or 1 (bf16)"); return SSS_EINVAL; }
+    const bool native = scan_dtype == exact_dtype;
+    if (!fused_shape_ok(d, scan_dtype) || (!native && (exact_dtype != DT_F32 || (scan_dtype != DT_SPLIT && scan_dtype != DT_F16)))) {
+        set_error("ip_topk_threshold: no scan of type %d for dtype %d, d %d", scan_dtype, exact_dtype, d);
+        return SSS_EINVAL;
+    }
+    if (!c_scan || (reinterpret_cast<uintptr_t>(c_scan) & 15)) { set_error("ip_topk_threshold: scan image missing or not 16-byte aligned"); return SSS_EINVAL; }
+    if (n >= (1L << 31) - 1024 || nsel >= (1L << 31)) { set_error("ip_topk_threshold: n and nsel must be < 2^31"); return SSS_EINVAL; }
+    if (k > THR_CAP) { set_error("ip_topk_threshold: k too large (max %d)", THR_CAP); return SSS_EINVAL; }
+    if (reinterpret_cast<uintptr_t>(ws) & 255) { set_error("ip_topk_threshold: workspace must be 256-byte aligned"); return SSS_EINVAL; }
+    const ScanPlan p = make_thr_plan(nsel, n, d, scan_dtype, THR_CAP);
+    if (ws_bytes < thr_head_bytes(nsel) + p.total_bytes) { set_error("ip_topk_threshold: workspace %zu < %zu", ws_bytes, thr_head_bytes(nsel) + p.total_bytes); return SSS_EWORKSPACE; }
+    char* w = reinterpret_cast<char*>(ws);
+    ThrArgs t;
+    t.Q = q; t.C = c_exact; t.qsel = qsel; t.nsel = (int)nsel; t.d = d; t.dtype = exact_dtype; t.k = k; t.cap = p.cap; t.n = n;
+    t.scan_dtype = scan_dtype; t.corpus_shift = corpus_shift; t.corpus_resid = corpus_resid; t.corpus_max_norm = corpus_max_norm;
+    t.id_offset = id_offset;
+    t.thr = reinterpret_cast<float*>(w);
+    t.cnt = reinterpret_cast<unsigned*>(w + (size_t)nsel * 4);
+    t.cand = reinterpret_cast<unsigned long long*>(w + thr_head_bytes(nsel));
+    t.D_out = D_out; t.I_out = I_out; t.status = status;
+    int rc = launch_thr_prepare(t, st);
+    if (rc) return rc;
+    ScanArgs a = {};
+    a.Q = q; a.C = c_scan; a.nq = (int)nsel; a.n = (int)n;
+    a.tiles_per_split = p.tiles_per_split; a.total_tiles = p.total_tiles;
+    a.S = p.S; a.G = p.G; a.J = 0; a.cert = 1; a.boot = 0; a.cap = p.cap;
+    a.slots = nullptr; a.cnt = t.cnt; a.maxlast = nullptr;
+    a.cand = const_cast<unsigned long long*>(t.cand);
+    a.qsel = qsel; a.thr = t.thr;
+    rc = launch_scan(scan_dtype, d, p.tile_rows, a, st);
+    if (rc) return rc;
+    return launch_select_all(t, st);
+}
+
 int ip_topk(const void* q, long nq, const void* c, long n, int d, int k, int dtype, long id_offset,
             float corpus_max_norm, float* D_out, long* I_out, int* status, int* unproven_count, void* state,
             size_t state_bytes, void* ws, size_t ws_bytes, hipStream_t st) {

@@ -12,7 +12,9 @@ struct LinProb {
     const float* w; long ldw; const float* bias;
     float* y; long ldy;
     long n; int m;
-    int act;                           // epilogue: 0 none, 1 relu, 2 tanh
+    int act;                           // epilogue: 0 none, 1 relu, 2 tanh, 3 sign, 4 tanh(tanh(.))
+    const float* post_scale = nullptr; // optional second epilogue stage, per output column: v = relu(v * post_scale + post_shift)
+    const float* post_shift = nullptr; //   (BatchNorm1d in eval mode followed by the reference MLP's relu, model/model.py:63-65)
     int tiles_m, tile_begin;           // filled by the launcher
 };
 struct LinBatch { LinProb p[4]; int nprob; int K; };

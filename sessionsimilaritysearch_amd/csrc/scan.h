@@ -65,8 +65,12 @@ struct ScanArgs {
     unsigned* cnt;
     unsigned long long* maxlast;
     unsigned long long* cand;
+    // threshold form only (k_scan<..., THR = true>): the compact query list and its per-query thresholds
+    const int* qsel = nullptr;
+    const float* thr = nullptr;
 };
 
+ScanPlan make_thr_plan(long nsel, long n, int d, int scan_dtype, int cap);
 int launch_scan(int dtype, int d, int tile_rows, const ScanArgs& a, hipStream_t st);
 
 struct SelectArgs {
@@ -90,8 +94,24 @@ struct SelectArgs {
 
 int launch_select(const SelectArgs& a, hipStream_t st);
 
-// per-device one-time setup flags (hipFuncSetAttribute is per device)
-constexpr int MAX_DEVICES = 64;
-int current_device();
+// Threshold rung (select.hip: k_thr_prepare, k_select_all; scan.hip: k_scan<..., THR = true>)
+struct ThrArgs {
+    const void* Q;                  // all queries [*, d] of the exact element type
+    const void* C;                  // the stored rows (re-score)
+    const int* qsel;                // [nsel] query rows to resolve
+    int nsel, d, dtype, k, cap;
+    long n;
+    int scan_dtype, corpus_shift;
+    float corpus_resid, corpus_max_norm;
+    long id_offset;
+    float* thr;                     // [nsel]   workspace
+    unsigned* cnt;                  // [nsel]   workspace
+    const unsigned long long* cand; // [nsel][cap] workspace
+    float* D_out;                   // [nq, k]: row q's k-th entry is read (lower bound), rows of resolved queries are rewritten
+    long* I_out;
+    int* status;                    // [nq]: set to 0 for resolved queries
+};
+int launch_thr_prepare(const ThrArgs& a, hipStream_t st);
+int launch_select_all(const ThrArgs& a, hipStream_t st);
 
 }  // namespace sss

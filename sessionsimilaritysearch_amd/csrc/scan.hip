@@ -84,7 +84,11 @@ __device__ __forceinline__ unsigned min8_sc1(const unsigned* p) {
 
 // NW = waves per workgroup: 8 (two per SIMD, 256 VGPRs each) or, for 1024-byte rows whose resident
 // queries alone take 128 VGPRs, 4 (one per SIMD, 512 VGPRs: no spills; NW * 32 queries per workgroup).
-template <int RB, int TR, int DT, int NW>
+// THR = true is the THRESHOLD form (the rung between the fused search and the exhaustive kernels,
+// ip_topk.hip: ip_topk_threshold): the queries are the compact list A.qsel, every lane compares against
+// its query's FIXED threshold A.thr[] (scan domain) instead of a running list, and every row above it is
+// appended to the query's candidate array -- no lists, no shared threshold, no bootstrap.
+template <int RB, int TR, int DT, int NW, bool THR = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     constexpr int H = TR / 64;                        // 64-row sub-steps per tile
     constexpr int CH = RB / 16;                       // 16-byte chunks per row
@@ -117,7 +121,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     // ---- resident queries: lane (r, h) holds 16-byte chunk 2u + h of its query row in qc[u]
     const int q_local = wave * 32 + r;
     const int q_glob = g * WGQ + q_local;
-    const int q_ld = q_glob < nq ? q_glob : nq - 1;
+    int q_ld = q_glob < nq ? q_glob : nq - 1;
+    if constexpr (THR) q_ld = A.qsel[q_ld];             // row of Q this lane's (compact) query lives in
     f32x4 qc[NU];
     if constexpr (DT == DT_SPLIT) {
         // f32 queries, split here: qc[u] = hi and qc[u + NU/2] = lo of k-slice u (k = 16u + 8h .. + 7),
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     float pend_s = -INFINITY;   // one parked candidate per lane (see the epilogue)
     int pend_i = -1;
     float tau = -INFINITY, thr = -INFINITY;
+    if constexpr (THR) thr = q_glob < nq ? A.thr[q_glob] : INFINITY;    // padding lanes never emit
     float rmax = -INFINITY;     // best score this lane has seen (published when cert == 1)
     float pub = -INFINITY;      // last value this lane published
 
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     int tile_hi = tile_lo + A.tiles_per_split;
     if (tile_hi > A.total_tiles) tile_hi = A.total_tiles;
     const int ntiles = tile_lo < tile_hi ? tile_hi - tile_lo : 0;
-    const bool use_tau = J > 0;
+    const bool use_tau = !THR && J > 0;
     const bool boot = use_tau && A.boot && ntiles > 0;
     const int niter = ntiles + (boot ? 1 : 0);
     // iteration -> tile: with the bootstrap the first tile is scanned at iteration 0 (max only)
@@ -400,6 +406,20 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         };
         walk(q0, 0); walk(q1, 4); walk(q2, 8); walk(q3, 12);     // ascending row order per lane
     };
+    // THR: every score above the lane's fixed threshold goes straight to the query's candidate array
+    // (rare by construction: the threshold sits an error bound below the k-th best score already known).
+    auto emit_block = [&](const f32x16& a, int base) {
+        float q0, q1, q2, q3;
+        const float m = block_max(a, q0, q1, q2, q3);
+        if (__builtin_amdgcn_ballot_w64(m > thr) == 0) return;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (a[j] > thr) {
+                const unsigned pos = atomicAdd(A.cnt + q_glob, 1u);
+                if (pos < (unsigned)A.cap) A.cand[(size_t)q_glob * A.cap + pos] = make_key(a[j], base + (j & 3) + 8 * (j >> 2));
+            }
+        }
+    };
     if (ntiles > 0) stage(0, tile_lo);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -486,11 +506,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             if (t % H == H - 1) tile_end(t / H);
         }
         if (!rare) break;
-        insert_block(acc0, (int)row0_of_step + 4 * h);
-        insert_block(acc1, (int)row0_of_step + 32 + 4 * h);
+        if constexpr (THR) {
+            emit_block(acc0, (int)row0_of_step + 4 * h);
+            emit_block(acc1, (int)row0_of_step + 32 + 4 * h);
+        } else {
+            insert_block(acc0, (int)row0_of_step + 4 * h);
+            insert_block(acc1, (int)row0_of_step + 32 + 4 * h);
+        }
         if (t % H == H - 1) tile_end(t / H);
         ++t;
     }
+    if constexpr (THR) return;
     list_insert<KP>(ls, li, pend_s, pend_i);   // no-op for lanes with an empty slot (-inf)
     // ---- append the real entries to the query's compact candidate array
     if (q_glob < nq) {
@@ -565,18 +591,45 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     return p;
 }
 
-template <int RB, int TR, int DT, int NW = 8>
-static int launch_one(const ScanArgs& a, hipStream_t st) {
+// Plan of the threshold form: G groups of compact queries x S corpus splits, 128-row tiles (64 for
+// 1024-byte rows), no threshold slots; cap = candidates kept per query.
+ScanPlan make_thr_plan(long nsel, long n, int d, int scan_dtype, int cap) {
+    ScanPlan p = {};
+    const int rb = d * elem_bytes(scan_dtype);
+    const int wgq = rb == 1024 ? 128 : WG_QUERIES;
+    p.G = (int)((nsel + wgq - 1) / wgq);
+    p.tile_rows = rb <= 512 ? 128 : 64;
+    p.S = pick_splits(n, p.G, p.tile_rows);
+    p.L = 2 * p.S;
+    p.total_tiles = (int)((n + p.tile_rows - 1) / p.tile_rows);
+    p.tiles_per_split = (p.total_tiles + p.S - 1) / p.S;
+    p.cap = cap;
+    p.total_bytes = align256((size_t)nsel * cap * 8);
+    return p;
+}
+
+template <int RB, int TR, int DT, int NW, bool THR>
+static int launch_form(const ScanArgs& a, hipStream_t st) {
     const size_t lds = 2 * (size_t)TR * RB + NW * 2048;      // two tile buffers + the threshold-slot staging
     static bool attr_done[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<RB, TR, DT, NW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<RB, TR, DT, NW, THR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((k_scan<RB, TR, DT, NW>), dim3(a.S * a.G), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((k_scan<RB, TR, DT, NW, THR>), dim3(a.S * a.G), dim3(NW * 64), lds, st, a);
     return check_launch("k_scan");
+}
+template <int RB, int TR, int DT, int NW = 8>
+static int launch_one(const ScanArgs& a, hipStream_t st) {
+    // the threshold form is compiled for one tile shape per row size (make_thr_plan picks it)
+    if (a.thr != nullptr) {
+        if constexpr (TR == (RB <= 512 ? 128 : 64)) return launch_form<RB, TR, DT, NW, true>(a, st);
+        set_error("scan: threshold form not built for %d-row tiles of %d-byte rows", TR, RB);
+        return SSS_EINVAL;
+    }
+    return launch_form<RB, TR, DT, NW, false>(a, st);
 }
 
 int launch_scan(int dtype, int d, int tile_rows, const ScanArgs& a, hipStream_t st) {

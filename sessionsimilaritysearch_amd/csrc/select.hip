@@ -464,6 +464,108 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
 }
 
 // ------------------------------------------------------------------------------------------
+// THRESHOLD RUNG (between the fused search and the exhaustive kernels).  A query the fused search left
+// unproven still has a valid LOWER BOUND of its k-th best score: lb = its k-th re-scored candidate.  A row
+// whose exact score could reach lb (or tie with it after the rounding to float32) has a scan score above
+//     thr = (lb - B - one float32 ulp of lb) / unscale          (B, unscale: as in decide_status)
+// so ONE more scan of the corpus for just those queries (k_scan<..., THR>) that keeps EVERY row above thr,
+// followed by the canonical re-score of all of them, is exact whatever the reason the proof failed -- near
+// ties inside the scan's error window and exact ties (duplicate rows) alike -- as long as the rows above thr
+// fit the candidate capacity; otherwise the query stays unproven and goes to the exhaustive kernels.
+//
+// k_thr_prepare: one wave per selected query: its threshold in the scan's domain, counter zeroed.
+__global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= A.nsel) return;
+    const int q = A.qsel[i];
+    const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
+    const char* qrow = reinterpret_cast<const char*>(A.Q) + (size_t)q * rb;
+    double qn2 = 0.0;
+    float q_amax = 0.f;
+    for (int kk = lane; kk < A.d; kk += 64) {
+        const float v = elem_to_f32(qrow, kk, A.dtype);
+        qn2 += (double)v * (double)v;
+        q_amax = fmaxf(q_amax, fabsf(v));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { qn2 += __shfl_xor(qn2, o); q_amax = fmaxf(q_amax, __shfl_xor(q_amax, o)); }
+    double rq2 = 0.0;
+    if (A.scan_dtype == DT_F16) {
+        const int sh = f16_shift(q_amax);
+        for (int kk = lane; kk < A.d; kk += 64) rq2 += f16_resid2(elem_to_f32(qrow, kk, A.dtype), sh);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rq2 += __shfl_xor(rq2, o);
+    }
+    if (lane != 0) return;
+    const double B = err_bound(A.d, A.scan_dtype, sqrt(qn2), (double)A.corpus_max_norm, (double)A.corpus_resid, sqrt(rq2));
+    const double unscale = A.scan_dtype == DT_F16 ? ldexp(1.0, -(A.corpus_shift + f16_shift(q_amax))) : 1.0;
+    const double lb = (double)A.D_out[(size_t)q * A.k + A.k - 1];          // -FLT_MAX when no k-th score is known
+    // rows the scan does NOT keep have scan score <= thr, hence exact score <= thr * unscale + B < lb - ulp32(lb)
+    const double t = (lb - B - 2.4e-7 * fabs(lb) - 1e-44) / unscale;
+    float thr = (float)t;                                                   // round to nearest, then step below
+    if ((double)thr >= t) thr = nextafterf(thr, -INFINITY);
+    if (!(lb > -3.0e38)) thr = -INFINITY;
+    A.thr[i] = thr;
+    A.cnt[i] = 0u;
+}
+
+// k_select_all: one workgroup per selected query: canonical float64 re-score of EVERY kept row, bitonic sort
+// by (score desc, id asc), first k written.  status[q] = 0 when the kept rows fit the capacity (and there are
+// at least min(k, n) of them); untouched otherwise.
+__global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, int cap_pow2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);             // [cap_pow2]
+    char* qrow = reinterpret_cast<char*>(keys + cap_pow2);
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int q = A.qsel[i];
+    const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
+    const int k = A.k;
+    const unsigned M = A.cnt[i];
+    const long need = (long)k < (long)A.n ? k : A.n;
+    if (M > (unsigned)A.cap || (long)M < need) return;                  // overflow (or NaNs): stays unproven
+    int M2 = 64;
+    while (M2 < (int)M) M2 <<= 1;
+    for (int v = tid; v < rb / 16; v += SORT_THREADS)
+        reinterpret_cast<f32x4*>(qrow)[v] = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.Q) + (size_t)q * rb)[v];
+    __syncthreads();
+    const unsigned long long* ck = A.cand + (size_t)i * A.cap;
+    for (int c = tid; c < M2; c += SORT_THREADS) {
+        unsigned long long key = 0ull;
+        if (c < (int)M) {
+            const int id = key_id(ck[c]);
+            const char* row = reinterpret_cast<const char*>(A.C) + (size_t)id * rb;
+            double acc = 0.0;
+            for (int v = 0; v < rb / 16; ++v)
+                acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
+            key = make_key((float)acc, id);
+        }
+        keys[c] = key;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= M2; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int x = tid; x < M2; x += SORT_THREADS) {
+                const int ixj = x ^ j;
+                if (ixj > x) {
+                    const unsigned long long a = keys[x], b = keys[ixj];
+                    const bool desc = (x & kk) == 0;
+                    if (desc ? a < b : a > b) { keys[x] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float* Dq = A.D_out + (size_t)q * k;
+    long* Iq = A.I_out + (size_t)q * k;
+    for (int j = tid; j < k; j += SORT_THREADS) {
+        if (j < (int)M) { Dq[j] = key_score(keys[j]); Iq[j] = (long)key_id(keys[j]) + A.id_offset; }
+        else { Dq[j] = -3.4028234663852886e38f; Iq[j] = -1; }
+    }
+    if (tid == 0) A.status[q] = 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // k-way merge of per-shard results (after the RCCL all-gather): [shards][nq][k] -> [nq][k] by
 // (score desc, id asc); ids < 0 are padding.  One thread per query (k*shards is tiny).
 __global__ void k_topk_merge(const float* __restrict__ D_in, long d_stride, const long* __restrict__ I_in,
@@ -520,6 +622,27 @@ int launch_select(const SelectArgs& a, hipStream_t st) {
     }
     hipLaunchKernelGGL(k_select_sort, dim3((unsigned)a.nq), dim3(SORT_THREADS), lds, st, a, cap_pow2);
     return check_launch("k_select_sort");
+}
+
+int launch_thr_prepare(const ThrArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_thr_prepare, dim3((unsigned)((a.nsel + 3) / 4)), dim3(256), 0, st, a);
+    return check_launch("k_thr_prepare");
+}
+
+int launch_select_all(const ThrArgs& a, hipStream_t st) {
+    const int rb = a.d * elem_bytes(a.dtype);
+    int cap_pow2 = 64;
+    while (cap_pow2 < a.cap) cap_pow2 <<= 1;
+    const size_t lds = (size_t)cap_pow2 * 8 + rb;
+    if (lds > 150 * 1024) { set_error("select_all: candidate capacity %d too large", a.cap); return SSS_EINVAL; }
+    static bool done[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!done[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_all), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL(k_select_all, dim3((unsigned)a.nsel), dim3(SORT_THREADS), lds, st, a, cap_pow2);
+    return check_launch("k_select_all");
 }
 
 int topk_merge(const float* D_in, long d_stride, const long* I_in, long i_stride, int shards, long nq, int k,

@@ -16,6 +16,10 @@ namespace sss {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// per-device one-time setup flags (hipFuncSetAttribute is per device); defined in scan.hip
+constexpr int MAX_DEVICES = 64;
+int current_device();
+
 // float -> uint32 whose unsigned order equals the float order (-inf lowest, +inf highest).
 __device__ __host__ __forceinline__ uint32_t f2ord(float f) {
     uint32_t u = __builtin_bit_cast(uint32_t, f);

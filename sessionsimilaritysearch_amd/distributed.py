@@ -59,11 +59,7 @@ class HipEngine:
         self.index.search_fused(q, k, (D, I, status), self.unproven)
 
     def fix_unproven(self, q, k, D, I, status):
-        bad = torch.nonzero(status).flatten()
-        if bad.numel():
-            self.index.search_exhaustive(q, k, D, I, bad, bounded=True)
-            self.index._note_fallbacks(k, q.shape[0], int(bad.numel()))
-        return int(bad.numel())
+        return self.index.fix_unproven(q, k, D, I, status)
 
     def merge(self, pack_all, chunk, shards, nq, k, D_out, I_out):
         from . import _lib

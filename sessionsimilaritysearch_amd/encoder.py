@@ -15,6 +15,7 @@ Out of scope, by design: the reference's BERT/ELECTRA text encoder
 from __future__ import annotations
 
 import ctypes
+import itertools
 import math
 from dataclasses import dataclass
 
@@ -145,9 +146,12 @@ class SessionEncoder:
     ``SessionBatch`` (or any object with the same attributes, e.g. a PyG hetero batch whose
     node stores carry ``x`` ids) on the encoder's device."""
 
+    _serials = itertools.count()
+
     def __init__(self, cfg: EncoderConfig, weights: dict, device=None, use_edge_weight: bool = False,
                  debug_nan_checks: bool = False, fused: bool = True):
         cfg.validate()
+        self._serial = next(SessionEncoder._serials)     # keys the per-batch workspace / argument-block cache
         if not torch.cuda.is_available():
             raise _lib.SssError("no HIP device available: the encoder runs on MI355X only")
         _lib.lib()
@@ -296,8 +300,7 @@ class SessionEncoder:
             .to(torch.int32).contiguous()
         if int(pb.pos_id.shape[0]) != pb.n_clicks + pb.Nq:
             raise _lib.SssError("product pos_emb_id must have sum(cnt) entries")
-        if int(pb.pos_id.max().item()) >= cfg.max_seq_len or int(pb.pos_id.min().item()) < 0:
-            raise IndexError("index out of range in self")      # what nn.Embedding raises upstream
+        self._check_ids(pb, check_min_pos=True)
         click_batch = pb.p_batch[src_p].contiguous()
         pb.pptr = torch.empty(pb.B + 1, dtype=torch.int32, device=dev)
         pb.qptr = torch.empty(pb.B + 1, dtype=torch.int32, device=dev)
@@ -361,9 +364,26 @@ class SessionEncoder:
         pb.w_pp = w_pp
         pb.qptr, pb.p_ptr, pb.pptr = bases[0], bases[1], bases[2]       # per-graph pointers come out of the scans
         pb.n_self_loop = min(Nq, Np) if cfg.self_loop_rule == "pyg_bipartite_global" else 0
-        if Xp + Nq and (int(pb.pos_id.max().item()) >= cfg.max_seq_len):
-            raise IndexError("index out of range in self")      # what nn.Embedding raises upstream
+        self._check_ids(pb)
         return pb
+
+    def _check_ids(self, pb, check_min_pos=False):
+        """Range checks of every index a kernel will dereference (positions, item / query feature ids),
+        ONE host read-back; out of range raises what ``nn.Embedding`` raises upstream."""
+        probes = []
+        if pb.pos_id.numel():
+            probes += [(pb.pos_id.max(), self.cfg.max_seq_len, False)]
+            if check_min_pos:
+                probes += [(pb.pos_id.min(), None, True)]
+        for ids, table in ((pb.p_ids, self.item_table), (pb.q_ids, self.query_table)):
+            if ids is not None and ids.numel() and table is not None:
+                probes += [(ids.max(), int(table.shape[0]), False), (ids.min(), None, True)]
+        if not probes:
+            return
+        vals = torch.stack([p[0].to(torch.int64) for p in probes]).tolist()
+        for v, (_, bound, is_min) in zip(vals, probes):
+            if (is_min and v < 0) or (not is_min and v >= bound):
+                raise IndexError("index out of range in self")
 
     def _features(self, ids, feat, table, n, buf=None):
         W = self.cfg.node_width
@@ -390,7 +410,12 @@ class SessionEncoder:
         allocation); the node buffers are allocated fresh when the caller asked for them."""
         cfg, dev = self.cfg, self.device
         h, D, P, W = cfg.h, cfg.d_out, cfg.max_seq_len, cfg.node_width
-        ws = getattr(pb, "_ws", None)
+        # The cache lives with the batch but belongs to THIS encoder: its buffers are sized by this
+        # configuration and its argument blocks hold raw pointers to these weights.
+        per_enc = getattr(pb, "_ws", None)
+        if per_enc is None:
+            per_enc = pb._ws = {}
+        ws = per_enc.get(self._serial)
         if ws is None:
             e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
             ldl = (D - P + 3) // 4 * 4
@@ -399,7 +424,7 @@ class SessionEncoder:
             ws = dict(NQ=e(pb.Nq, W), NP=e(pb.Np, W), Yp=e(pb.Np, 7 * h + ALPHA_PAD), Yq=e(pb.Nq, h + ALPHA_PAD),
                       T=torch.zeros((pb.Np + pb.Nq, KT), dtype=torch.float32, device=dev),     # pad columns stay zero
                       AC=e(pb.Np + pb.Nq, 2 * D), calls={})
-            pb._ws = ws
+            per_enc[self._serial] = ws
         if fresh_nodes:
             ws = dict(ws, NQ=torch.empty((pb.Nq, W), dtype=torch.float32, device=dev),
                       NP=torch.empty((pb.Np, W), dtype=torch.float32, device=dev), calls={})

@@ -30,6 +30,7 @@ F16_SCAN_DIMS = (128, 256, 512)                                  # scaled-f16 im
 AUTO_F16_MAX_K = 16
 AUTO_SPLIT_MAX_K = 128
 AUTO_ESCALATE = 0.005
+AUTO_DECAY_SEARCHES = 64        # clean searches at an escalated level before the class steps back down one scan
 _LADDER = ("f16", "split", "f32")
 FUSED_MAX_K = 500
 DTYPE_CODE = {"f32": 0, "bf16": 1}                               # include/sss.h: dtype
@@ -119,8 +120,14 @@ class FlatIndex:
     ``"f32"`` scans the float32 rows on the f32 MFMA (error ~ d 2^-24) and needs no second image;
     ``"auto"`` (default) takes "f16" for k <= 16 where the shape allows, "split" up to k = 128 and
     "f32" beyond (the scores around rank k lie closer together as k grows), and moves a k class one
-    scan up when a search left more than 0.5 % of its queries (at least 4) to the fallback.  Images are built on
-    first use (``prepare(k)`` does it ahead of time) and extended as rows are added."""
+    scan up when a search left more than 0.5 % of its queries (at least 4) unproven (back down after 64
+    clean searches).  Images are built on first use (``prepare(k)`` does it ahead of time) and extended
+    as rows are added.
+
+    Queries a scan leaves unproven are resolved in two further stages, both exact: the THRESHOLD RUNG
+    (``search_threshold``: one more matrix-core scan for just those queries that keeps every row able to
+    reach the k-th score already known, near ties and duplicate rows alike) and, for what exceeds its
+    capacity, the exhaustive kernels (``search_exhaustive``)."""
 
     def __init__(self, d: int, metric: str = "ip", device=None, dtype: str = "f32", scan: str | None = None):
         if metric not in ("ip", "l2"):
@@ -136,6 +143,7 @@ class FlatIndex:
         self.scan = scan
         self.last_scan = None           # the scan the last fused search used
         self._auto_level = {}           # scan="auto": k class -> lowest ladder level still allowed
+        self._auto_clean = {}           # scan="auto": k class -> consecutive clean searches at the escalated level
         self.d = int(d)
         self.metric = metric
         self.dtype = dtype
@@ -158,6 +166,7 @@ class FlatIndex:
         self._state = None              # per-query state words of sss_ip_topk: zeroed once, kept zero by the kernels
         self.id_offset = 0              # global id of row 0 (row-sharded corpora)
         self.last_fallback_queries = 0  # queries of the last search() re-run exhaustively
+        self.last_rescan_queries = 0    # queries of the last search() the fused scan left unproven (threshold rung first)
 
     @property
     def ntotal(self) -> int:
@@ -175,6 +184,8 @@ class FlatIndex:
         self._store[n_old:n_old + x.shape[0]] = x
         self._xb = self._store[:n_old + x.shape[0]]
         self._norm_max(x)
+        self._auto_level.clear()        # a different corpus: the escalation was earned on the old one
+        self._auto_clean.clear()
 
     def scan_for(self, k: int) -> str:
         """Which candidate scan a fused search for k results uses ("" = none: exhaustive path)."""
@@ -184,20 +195,48 @@ class FlatIndex:
             return "native" if self.d in FUSED_DIMS[self.dtype] else ""
         want = self.scan
         if want == "auto":
-            level = 0 if k <= AUTO_F16_MAX_K else 1 if k <= AUTO_SPLIT_MAX_K else 2
-            want = _LADDER[max(level, self._auto_level.get(self._k_class(k), 0))]
-        if want == "f16" and self.d not in F16_SCAN_DIMS:
+            level = max(self._k_class(k), self._auto_level.get(self._k_class(k), 0))
+            served = [s for s in _LADDER[level:] if self._scan_served(s)]
+            # nothing at or above the wanted level fits this d (e.g. d = 512: only the f16 image does):
+            # stay on the fastest scan that does rather than fall off the ladder
+            served = served or [s for s in _LADDER if self._scan_served(s)]
+            return served[0] if served else ""
+        if want == "f16" and not self._scan_served("f16"):
             want = "split"
-        return want if (want == "f16" or self.d in FUSED_DIMS["f32"]) else ""
+        return want if self._scan_served(want) else ""
+
+    def _scan_served(self, scan: str) -> bool:
+        """Does a fused kernel exist for this scan at this d?"""
+        return self.d in (F16_SCAN_DIMS if scan == "f16" else FUSED_DIMS["f32"])
+
+    def next_scan(self, scan: str) -> str:
+        """The next scan up the precision ladder that this d can run ("" = none)."""
+        if self.dtype != "f32" or scan not in _LADDER:
+            return ""
+        return next((s for s in _LADDER[_LADDER.index(scan) + 1:] if self._scan_served(s)), "")
 
     @staticmethod
     def _k_class(k: int) -> int:
         return 0 if k <= AUTO_F16_MAX_K else 1 if k <= AUTO_SPLIT_MAX_K else 2
 
     def _note_fallbacks(self, k: int, nq: int, bad: int):
-        """scan="auto": escalate this k class when too many queries needed the exhaustive path."""
-        if self.scan == "auto" and nq >= 32 and bad >= 4 and bad > AUTO_ESCALATE * nq and self.last_scan in _LADDER[:-1]:
-            self._auto_level[self._k_class(k)] = _LADDER.index(self.last_scan) + 1
+        """scan="auto": move this k class one scan up when too many queries of a search were left
+        unproven by it -- only to a scan this d can run -- and back down one scan after
+        AUTO_DECAY_SEARCHES consecutive clean searches (one near-duplicate-heavy batch does not demote
+        the index for good)."""
+        if self.scan != "auto" or self.last_scan not in _LADDER:
+            return
+        kc = self._k_class(k)
+        if nq >= 32 and bad >= 4 and bad > AUTO_ESCALATE * nq:
+            up = self.next_scan(self.last_scan)
+            if up:
+                self._auto_level[kc] = _LADDER.index(up)
+            self._auto_clean[kc] = 0
+        elif self._auto_level.get(kc, 0) > kc and nq >= 32:
+            self._auto_clean[kc] = self._auto_clean.get(kc, 0) + (1 if bad == 0 else 0)
+            if self._auto_clean[kc] >= AUTO_DECAY_SEARCHES:
+                self._auto_level[kc] -= 1
+                self._auto_clean[kc] = 0
 
     def _grow_image(self, img, done, width, tdtype):
         """The image tensor with room for every row of the store, its first `done` rows kept."""
@@ -291,6 +330,8 @@ class FlatIndex:
         self._f16, self._f16_done = None, 0
         self._amax_t.zero_()
         self._resid_t.zero_()
+        self._auto_level.clear()
+        self._auto_clean.clear()
         return self
 
     def corpus_max_norm(self) -> float:
@@ -349,6 +390,63 @@ class FlatIndex:
         _lib.check(rc, "sss_ip_topk")
         return D, I, status
 
+    def rung_scan(self) -> str:
+        """The scan the threshold rung uses: the one-pass f16 image where the shape has one (cheapest pass
+        over the corpus; its wider error window only means a few more rows to re-score), else the index's
+        own rows."""
+        if self.metric != "ip" or self.ntotal == 0:
+            return ""
+        if self.dtype != "f32":
+            return "native" if self.d in FUSED_DIMS[self.dtype] else ""
+        if self.scan in ("auto", "f16") and self._scan_served("f16"):
+            return "f16"
+        if self.scan == "split" and self._scan_served("split"):
+            return "split"
+        return "f32" if self._scan_served("f32") else ("f16" if self._scan_served("f16") else "")
+
+    def search_threshold(self, q: torch.Tensor, k: int, D: torch.Tensor, I: torch.Tensor, status: torch.Tensor, rows):
+        """Threshold rung (``sss_ip_topk_threshold``) for the query rows ``rows`` a fused search left
+        unproven: one more scan for just those queries keeps every corpus row that could still reach the
+        k-th score already known (column k-1 of their rows of D) and re-scores them all.  Resolved rows of
+        D / I are rewritten and their status set to 0; returns the rows still unproven."""
+        mode = self.rung_scan()
+        if mode == "" or rows.numel() == 0 or k > 8192:
+            return rows
+        L = _lib.lib()
+        if mode == "f16":
+            self._ensure_f16()
+            image, code, shift, resid = self._f16, 3, self._c_shift, self.corpus_resid_norm()
+        elif mode == "split":
+            self._ensure_split()
+            image, code, shift, resid = self._split, 2, 0, 0.0
+        else:
+            image, code, shift, resid = self._xb, DTYPE_CODE[self.dtype], 0, 0.0
+        sel = rows.to(device=self.device, dtype=torch.int32).contiguous()
+        n = self.ntotal
+        ws = self._workspace(L.sss_ip_topk_threshold_workspace_bytes(sel.numel(), n, self.d, code))
+        rc = L.sss_ip_topk_threshold(q.data_ptr(), sel.data_ptr(), sel.numel(), self._xb.data_ptr(), DTYPE_CODE[self.dtype],
+                                     image.data_ptr(), code, shift, resid, n, self.d, k, self.id_offset,
+                                     self.corpus_max_norm(), D.data_ptr(), I.data_ptr(), status.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device))
+        _lib.check(rc, "sss_ip_topk_threshold")
+        return sel[status[sel.long()] != 0]
+
+    def fix_unproven(self, q: torch.Tensor, k: int, D: torch.Tensor, I: torch.Tensor, status: torch.Tensor) -> int:
+        """Make the result of a fused search exact for every query: unproven ones (status != 0) go through
+        the threshold rung, what that leaves (more tied rows than its capacity) through the exhaustive
+        kernels.  One host sync per stage that has work.  Returns the number of queries the fused scan
+        had left unproven."""
+        bad = torch.nonzero(status).flatten()
+        nbad = int(bad.numel())
+        self.last_rescan_queries, self.last_fallback_queries = nbad, 0
+        if nbad:
+            left = self.search_threshold(q, k, D, I, status, bad)
+            if left.numel():
+                self.last_fallback_queries = int(left.numel())
+                self.search_exhaustive(q, k, D, I, left, bounded=True)
+        self._note_fallbacks(k, q.shape[0], nbad)
+        return nbad
+
     def search_exhaustive(self, q: torch.Tensor, k: int, D: torch.Tensor, I: torch.Tensor, rows=None, bounded=False):
         """Exhaustive exact path for query rows ``rows`` (all when None); writes into D / I.
         ``bounded``: D[rows, k-1] holds a valid lower bound of each query's k-th best score (what a
@@ -384,7 +482,7 @@ class FlatIndex:
         nq = q.shape[0]
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
-        self.last_fallback_queries = 0
+        self.last_fallback_queries = self.last_rescan_queries = 0
         if nq == 0:
             return D, I
         if self.ntotal == 0:
@@ -396,11 +494,7 @@ class FlatIndex:
         if self.fused_ok(k):
             status = torch.empty((nq,), dtype=torch.int32, device=self.device)
             self.search_fused(q, k, (D, I, status))
-            bad = torch.nonzero(status).flatten()
-            if bad.numel():
-                self.last_fallback_queries = int(bad.numel())
-                self.search_exhaustive(q, k, D, I, bad, bounded=True)
-                self._note_fallbacks(k, nq, int(bad.numel()))
+            self.fix_unproven(q, k, D, I, status)
         else:
             self.last_fallback_queries = nq
             self.search_exhaustive(q, k, D, I)
@@ -466,6 +560,7 @@ class BinaryFlatIndex:
         self._w = next(w for w in self.WIDTHS if w >= self.code_bytes)     # stored (padded) row bytes
         self.device = _dev(device)
         self._codes = torch.empty((0, self._w), dtype=torch.uint8, device=self.device)
+        self._store = self._codes       # backing storage of _codes (grown geometrically by add())
         self._ws = None
         self.id_offset = 0
         self.last_fallback_queries = 0
@@ -487,7 +582,15 @@ class BinaryFlatIndex:
         return x.contiguous()
 
     def add(self, codes):
-        self._codes = torch.cat([self._codes, self._rows(codes)], dim=0)
+        x = self._rows(codes)
+        n_old = self.ntotal
+        if n_old + x.shape[0] > self._store.shape[0]:          # amortised growth, as FlatIndex.add
+            cap = max(n_old + x.shape[0], 2 * self._store.shape[0])
+            store = torch.empty((cap, self._w), dtype=torch.uint8, device=self.device)
+            store[:n_old] = self._codes
+            self._store = store
+        self._store[n_old:n_old + x.shape[0]] = x
+        self._codes = self._store[:n_old + x.shape[0]]
 
     def _workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
@@ -504,12 +607,12 @@ class BinaryFlatIndex:
         self.last_fallback_queries = 0
         if nq and n:
             st = _lib.stream_ptr(self.device)
-            bad = None
-            ws = self._workspace(L.sss_hamming_topk_workspace_bytes(nq, n))
-            status = torch.empty((nq,), dtype=torch.int32, device=self.device)
-            rc = L.sss_hamming_topk(q.data_ptr(), nq, self._codes.data_ptr(), n, self._w, k, self.id_offset, D.data_ptr(),
-                                    I.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), st)
-            if rc == 0:
+            if k <= L.sss_hamming_topk_capacity(nq, n):
+                ws = self._workspace(L.sss_hamming_topk_workspace_bytes(nq, n))
+                status = torch.empty((nq,), dtype=torch.int32, device=self.device)
+                rc = L.sss_hamming_topk(q.data_ptr(), nq, self._codes.data_ptr(), n, self._w, k, self.id_offset, D.data_ptr(),
+                                        I.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(), st)
+                _lib.check(rc, "sss_hamming_topk")
                 bad = torch.nonzero(status).flatten().to(torch.int32)
             else:                               # k beyond the fused capacity: everything through the exhaustive path
                 bad = torch.arange(nq, dtype=torch.int32, device=self.device)

@@ -6,14 +6,18 @@ CSR-by-target + segment kernels:
 * ``GraphPooling``      <- ``model/gnn.py:123-143`` (mean / add / max + Linear; dropout is identity in eval)
 * ``AttentionPooling``  <- ``model/gnn.py:145-161`` (row-wise dot instead of the dense [n_nodes, B] matrix)
 * ``SRGNNPooling``      <- ``model/gnn.py:164-181``
-* ``MLPHead``           <- ``model/model.py:40-73`` in eval mode (BatchNorm folded into the Linear at
-                           weight-preparation time; ReLU after every hidden layer, tanh at the end when
-                           ``last_act``; ``F.dropout`` without ``training=`` is a no-op only for p = 0,
-                           which is what the scripts use)
+* ``MLPHead``           <- ``model/model.py:40-73`` in eval mode (BatchNorm's eval-mode affine + the relu the
+                           reference applies to it run as a second epilogue stage of the Linear's GEMM; tanh at
+                           the end when ``last_act``; ``F.dropout`` without ``training=`` is a no-op only for
+                           p = 0, which is what the scripts use)
+* ``BinarizeHead``      <- ``model/model.py:105-138`` in eval mode: ``sign(lin1(tanh(mlp(x))))`` (with ``jump``:
+                           ``lin1([tanh(mlp(x)) ; x])``) -- the +-1 codes ``pack_sign_bits`` / ``BinaryFlatIndex``
+                           take (fine_tune_ours.py:839-843)
 
 Every arithmetic step runs in ``libsss.so`` (``sss_csr_mean``, ``sss_segment_reduce``,
 ``sss_attention_dot_pool``, ``sss_pool_attention``, ``sss_linear_grouped``); torch owns memory only.
-Weights are flat ``{name: tensor}`` dicts; widths must be multiples of 32 and <= 256.
+Weights are flat ``{name: tensor}`` dicts; conv / pool widths must be multiples of 32 and <= 256, the MLP /
+binarize heads take any width (the reference's 1600 -> 3000 -> 2000 -> 250).
 """
 from __future__ import annotations
 
@@ -27,20 +31,35 @@ def _st(dev):
     return _lib.stream_ptr(dev)
 
 
-def _prob(x, w, bias, y, n, m, act=0):
+def _prob(x, w, bias, y, n, m, act=0, post=None):
     return _lib.LinearProblem(x=x.data_ptr(), ldx=x.stride(0), ids=0, table=0, xcopy=0, ld_xcopy=0, w=w.data_ptr(),
                               ldw=w.stride(0), bias=0 if bias is None else bias.data_ptr(), y=y.data_ptr(), ldy=y.stride(0),
-                              n=n, m=m, act=act)
+                              n=n, m=m, act=act, post_scale=0 if post is None else post[0].data_ptr(),
+                              post_shift=0 if post is None else post[1].data_ptr())
 
 
-def linear(x, w, bias=None, act=0, out=None):
-    """y = act(x w^T + bias) through ``sss_linear_grouped`` (act: 0 none, 1 relu, 2 tanh)."""
-    n, k = x.shape
+def linear(x, w, bias=None, act=0, out=None, post=None):
+    """y = act(x w^T + bias) through ``sss_linear_grouped`` (act: 0 none, 1 relu, 2 tanh, 3 sign,
+    4 tanh(tanh(.))); ``post = (scale, shift)``: then ``relu(y * scale + shift)`` per column.  ``x`` may be
+    wider than ``w`` has columns only by zero padding on both sides (K = w.shape[1], a multiple of 32)."""
+    n, k = x.shape[0], w.shape[1]
     m = w.shape[0]
     if out is None:
         out = torch.empty((n, m), dtype=torch.float32, device=x.device)
-    arr = (_lib.LinearProblem * 1)(_prob(x, w, bias, out, n, m, act))
+    arr = (_lib.LinearProblem * 1)(_prob(x, w, bias, out, n, m, act, post))
     _lib.check(_lib.lib().sss_linear_grouped(arr, 1, k, _st(x.device)), "sss_linear_grouped")
+    return out
+
+
+def _pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def _pad_cols(w, dev):
+    """Weight [m, k] -> device [m, pad32(k)] with zero columns (the GEMM's K is a multiple of 32)."""
+    w = w.detach().to(torch.float32)
+    out = torch.zeros((w.shape[0], _pad32(w.shape[1])), dtype=torch.float32, device=dev)
+    out[:, :w.shape[1]] = w
     return out
 
 
@@ -161,29 +180,112 @@ class SRGNNPooling:
 
 class MLPHead:
     """``MLP`` in eval mode.  weights: ``layers.{i}.w/.b`` for the Linear layers (in order) and
-    ``bn.{i}.mean/.var/.gamma/.beta`` for the BatchNorm1d after each but the last (eps 1e-5)."""
+    ``bn.{i}.mean/.var/.gamma/.beta`` for the BatchNorm1d after each but the last (eps 1e-5).  Any widths:
+    activations are kept in buffers padded to a multiple of 32 columns (zero pad), weights likewise."""
 
     def __init__(self, weights, n_hidden_layers, device, last_act=True, jump=False):
         self.jump, self.last_act = jump, last_act
         self.hidden = []
         f64 = lambda t: t.detach().to(torch.float64)
         for i in range(n_hidden_layers + 1):
-            w, b = f64(weights[f"layers.{i}.w"]), f64(weights[f"layers.{i}.b"])
             s = f64(weights[f"bn.{i}.gamma"]) / torch.sqrt(f64(weights[f"bn.{i}.var"]) + 1e-5)
             # the reference applies relu to EVERY module of layers[:-1], Linear and BatchNorm alike
-            # (model/model.py:63-65): relu(bn(relu(lin(x)))).  The inner relu stays a kernel epilogue,
-            # the BatchNorm affine is the next (diagonal) step.
-            self.hidden.append((_d(w.float(), device), _d(b.float(), device), _d(torch.diag(s).float(), device),
+            # (model/model.py:63-65): relu(bn(relu(lin(x)))).  Both stages are epilogue steps of the Linear's GEMM:
+            # act = relu, then the BatchNorm eval affine + relu per output column.
+            self.hidden.append((_pad_cols(weights[f"layers.{i}.w"], device), _d(weights[f"layers.{i}.b"], device),
+                                _d(s.float(), device),
                                 _d((f64(weights[f"bn.{i}.beta"]) - f64(weights[f"bn.{i}.mean"]) * s).float(), device)))
         last = n_hidden_layers + 1
-        self.wl, self.bl = _d(weights[f"layers.{last}.w"], device), _d(weights[f"layers.{last}.b"], device)
+        self.n_in = int(weights["layers.0.w"].shape[1])
+        self.n_hidden = int(weights["layers.0.w"].shape[0])
+        self.wl_raw = weights[f"layers.{last}.w"]
+        if jump:            # last Linear reads [inp ; hidden]: pad each part of K separately so both stay 32-aligned
+            wl = torch.zeros((self.wl_raw.shape[0], _pad32(self.n_in) + _pad32(self.n_hidden)))
+            wl[:, :self.n_in] = self.wl_raw[:, :self.n_in]
+            wl[:, _pad32(self.n_in):_pad32(self.n_in) + self.n_hidden] = self.wl_raw[:, self.n_in:]
+            self.wl = _d(wl, device)
+        else:
+            self.wl = _pad_cols(self.wl_raw, device)
+        self.bl = _d(weights[f"layers.{last}.b"], device)
+        self.n_out = int(self.wl_raw.shape[0])
+
+    def _in_buffer(self, x):
+        """x [n, n_in] -> a buffer whose row is [x | 0-pad | hidden | 0-pad] (jump) or [x | 0-pad]."""
+        n, dev = x.shape[0], x.device
+        kin, kh = _pad32(self.n_in), _pad32(self.n_hidden)
+        if not self.jump and kin == self.n_in and x.is_contiguous():
+            return x, None
+        buf = torch.zeros((n, kin + (kh if self.jump else 0)), dtype=torch.float32, device=dev)
+        buf[:, :self.n_in] = x
+        return buf[:, :kin], buf
 
     @torch.no_grad()
-    def forward(self, x):
-        inp = x
-        for w, b, s, t in self.hidden:
-            y = linear(x, w, b, act=1)                              # relu(lin(x))
-            x = linear(y, s, t, act=1)                              # relu(batchnorm_eval(.)): the affine as a diagonal transform
+    def forward(self, x, act_last=None, out=None):
+        n, dev = x.shape[0], x.device
+        kin, kh = _pad32(self.n_in), _pad32(self.n_hidden)
+        xin, whole = self._in_buffer(x)
+        cur = xin
+        for li, (w, b, s, t) in enumerate(self.hidden):
+            last_hidden = li == len(self.hidden) - 1
+            if self.jump and last_hidden:
+                dst = whole[:, kin:kin + self.n_hidden]              # lands next to the input: the concat is free
+            else:
+                full = torch.zeros((n, kh), dtype=torch.float32, device=dev)
+                dst = full[:, :self.n_hidden]
+            linear(cur, w, b, act=1, out=dst, post=(s, t))           # relu(bn(relu(lin(x))))
+            cur = whole[:, kin:kin + kh] if (self.jump and last_hidden) else full
+        src = whole if self.jump else cur
+        if act_last is None:
+            act_last = 2 if self.last_act else 0
+        return linear(src, self.wl, self.bl, act=act_last, out=out)
+
+    __call__ = forward
+
+
+class BinarizeHead:
+    """``BinarizeHead`` in eval mode (model/model.py:105-138): ``sign(lin1(h))`` with ``h = x`` when there is
+    no mlp, else ``h = tanh(mlp(x))`` (``jump``: ``h = [tanh(mlp(x)) ; x]``).  The reference returns
+    ``(sign(out) - tanh(out)).detach() + tanh(out)``, which is exactly ``sign(out)`` in float32 (for |t| < 1 the
+    rounding of ``1 - t`` is undone by adding ``t`` back: the sum lies within half an ulp of 1).  weights:
+    ``lin1.w [n_output, n_input]``, ``lin1.b``; ``mlp`` is an ``MLPHead`` (its ``last_act`` tanh is applied, then
+    the head's own tanh: ``tanh(tanh(.))`` in one epilogue).  ``forward(x, pre_sign=True)`` returns ``lin1(h)``
+    before the sign (what the parity test compares)."""
+
+    def __init__(self, weights, mlp, device, jump=False):
+        self.mlp, self.jump = mlp, jump
+        self.n_in = int(weights["lin1.w"].shape[1])
+        w = weights["lin1.w"]
+        if mlp is not None and jump:
+            m_out = mlp.n_out
+            wl = torch.zeros((w.shape[0], _pad32(m_out) + _pad32(self.n_in - m_out)))
+            wl[:, :m_out] = w[:, :m_out]
+            wl[:, _pad32(m_out):_pad32(m_out) + self.n_in - m_out] = w[:, m_out:]
+            self.w1 = _d(wl, device)
+        else:
+            self.w1 = _pad_cols(w, device)
+        self.b1 = _d(weights["lin1.b"], device)
+
+    @torch.no_grad()
+    def forward(self, x, pre_sign=False):
+        n, dev = x.shape[0], x.device
+        act = 0 if pre_sign else 3
+        if self.mlp is None:
+            k = self.w1.shape[1]
+            if x.shape[1] != k or not x.is_contiguous():
+                buf = torch.zeros((n, k), dtype=torch.float32, device=dev)
+                buf[:, :x.shape[1]] = x
+                x = buf
+            return linear(x, self.w1, self.b1, act=act)
+        m_out = self.mlp.n_out
+        km = _pad32(m_out)
         if self.jump:
-            x = torch.cat([inp, x], dim=1)
-        return linear(x, self.wl, self.bl, act=2 if self.last_act else 0)
+            buf = torch.zeros((n, self.w1.shape[1]), dtype=torch.float32, device=dev)
+            buf[:, km:km + x.shape[1]] = x
+            h = buf
+        else:
+            buf = torch.zeros((n, km), dtype=torch.float32, device=dev)
+            h = buf
+        self.mlp.forward(x, act_last=4 if self.mlp.last_act else 2, out=buf[:, :m_out])    # tanh(mlp(x))
+        return linear(h, self.w1, self.b1, act=act)
+
+    __call__ = forward

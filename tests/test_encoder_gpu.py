@@ -349,6 +349,35 @@ def test_native_graph_builder_is_bit_exact(cuda, seed, n, vocab, loops):
     assert eq(got.pptr, ref.pptr) and eq(got.qptr, ref.qptr) and got.n_self_loop == ref.n_self_loop
     if vocab < 1000:
         assert torch.equal(enc(got), enc(ref))
+    if n <= 2500:
+        # ... and directly against the ORACLE (oracle/graph_ref.py: the per-session restatement of
+        # sequence_to_graph + Batch.from_data_list, util_amazon_filtered.py:128-142,180-218), converted
+        # to CSR-by-target here with a plain numpy stable sort -- no product code in between.
+        from oracle import graph_ref
+        o = graph_ref.collate([graph_ref.session_to_graph(s_) for s_ in graph_ref.actions_to_sessions(acts)])
+        Nq, Np = len(o["q_x"]), len(o["p_x"])
+        assert (got.Nq, got.Np, got.B) == (Nq, Np, n)
+
+        def csr(src, dst, n_dst, w=None):
+            order = np.argsort(dst, kind="stable")
+            rowptr = np.zeros(n_dst + 1, np.int64)
+            np.cumsum(np.bincount(dst, minlength=n_dst), out=rowptr[1:])
+            return rowptr, src[order], None if w is None else w[order]
+        npy = lambda t: t.cpu().numpy().astype(np.int64)
+        for name, (rp, col, w) in (("csr_qp", csr(o["qp0"], o["qp1"], Np)), ("csr_pq", csr(o["qp1"], o["qp0"], Nq)),
+                                   ("csr_pp", csr(o["pp0"], o["pp1"], Np, o["pp_w"]))):
+            assert np.array_equal(npy(getattr(got, name)[0]), rp), name + ".rowptr vs oracle"
+            assert np.array_equal(npy(getattr(got, name)[1]), col), name + ".col vs oracle"
+            if w is not None:
+                assert np.array_equal(got.csr_pp[2].cpu().numpy(), w), name + ".weight vs oracle"
+        assert np.array_equal(npy(got.q_ids), o["q_x"]) and np.array_equal(npy(got.p_ids), o["p_x"])
+        assert np.array_equal(npy(got.q_batch), o["q_batch"]) and np.array_equal(npy(got.p_batch), o["p_batch"])
+        src_row = np.r_[np.repeat(np.arange(Np), o["p_cnt"]), np.arange(Nq)]
+        assert np.array_equal(npy(got.src_row), src_row)
+        assert np.array_equal(npy(got.pos_id), np.r_[o["p_pos"], o["q_pos"]])
+        clicks_per_graph = np.bincount(o["p_batch"], weights=o["p_cnt"], minlength=n).astype(np.int64)
+        assert np.array_equal(npy(got.pptr), np.r_[0, np.cumsum(clicks_per_graph)])
+        assert np.array_equal(npy(got.qptr), np.r_[0, np.cumsum(np.bincount(o["q_batch"], minlength=n))])
 
 
 def test_native_graph_builder_edge_cases(cuda):
@@ -373,3 +402,41 @@ def test_native_graph_builder_edge_cases(cuda):
     too_long = S.ActionTable(np.array([0, 65]), np.zeros(65, bool), np.arange(1, 66), np.zeros(65, np.int64))
     with pytest.raises(_lib.SssError):
         enc.prepare_actions(too_long)
+
+
+# ---------------------------------------------------------------------------- cache ownership, id range checks
+def test_two_encoders_share_one_prepared_batch(cuda):
+    """The fused forward caches its workspace / argument blocks with the PreparedBatch; the cache is keyed
+    by encoder, so a second encoder (other weights, other widths) over the SAME prepared batch uses its own."""
+    acts = S.synthetic_actions(300, 11, 500, 33)
+    cfg_a = EncoderConfig(d_in=32, h=32, n_layers=2, d_out=64, n_items=500, n_query=33)
+    cfg_b = EncoderConfig(d_in=32, h=64, n_layers=1, d_out=96, n_items=500, n_query=33)
+    wa, wb = init_weights(cfg_a, 1), init_weights(cfg_b, 2)
+    wb["item_table"], wb["query_table"] = wa["item_table"], wa["query_table"]
+    enc_a, enc_b = SessionEncoder(cfg_a, wa, cuda), SessionEncoder(cfg_b, wb, cuda)
+    pb = enc_a.prepare_actions(acts)
+    out_a1 = enc_a(pb).clone()
+    out_b = enc_b(pb).clone()           # same pb, different encoder
+    out_a2 = enc_a(pb)
+    batch = S.build_batch(acts).to_torch("cpu")
+    ref_a = gnn_ref.encoder_forward(batch, wa, cfg_a.n_layers).numpy()
+    ref_b = gnn_ref.encoder_forward(batch, wb, cfg_b.n_layers).numpy()
+    assert torch.equal(out_a1, out_a2)
+    assert np.abs(out_a1.cpu().numpy() - ref_a).max() < TOL * max(1.0, np.abs(ref_a).max())
+    assert np.abs(out_b.cpu().numpy() - ref_b).max() < TOL * max(1.0, np.abs(ref_b).max())
+    del enc_a                           # freeing the first encoder must not matter to the second
+    assert torch.equal(enc_b(pb), out_b)
+
+
+def test_feature_ids_are_range_checked(cuda):
+    """An item / query id outside its table raises what nn.Embedding raises upstream (IndexError), before any launch."""
+    cfg = EncoderConfig(d_in=32, h=32, n_layers=1, d_out=64, n_items=50, n_query=9)
+    enc = SessionEncoder(cfg, init_weights(cfg, 3), cuda)
+    ok = S.ActionTable(np.array([0, 3]), np.array([True, False, False]), np.array([0, 49, 7]), np.array([8, 0, 0]))
+    enc(enc.prepare_actions(ok))
+    for item, tok in ((50, 8), (49, 9), (-1, 8)):
+        bad = S.ActionTable(np.array([0, 3]), np.array([True, False, False]), np.array([0, item, 7]), np.array([tok, 0, 0]))
+        with pytest.raises(IndexError):
+            enc.prepare_actions(bad)
+        with pytest.raises(IndexError):
+            enc.prepare(S.build_batch(bad).to(cuda))

@@ -71,7 +71,7 @@ def test_scan_kernel_variants_match_oracle(cuda, scan_mode, nq, n, d):
     assert idx.last_scan == scan_mode
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
-    assert idx.last_fallback_queries <= max(2, nq // 100)
+    assert idx.last_rescan_queries <= max(2, nq // 100)
 
 
 def test_random_data_is_proven_exact_without_fallback(cuda, scan):
@@ -79,7 +79,7 @@ def test_random_data_is_proven_exact_without_fallback(cuda, scan):
     q, c = _unit(rng, 512, 128), _unit(rng, 100000, 128)
     idx = _index(c, cuda, scan=scan)
     D, I = idx.search(q, 10)
-    assert idx.last_fallback_queries == 0
+    assert idx.last_rescan_queries == 0
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
@@ -95,7 +95,7 @@ def test_every_k_regime_is_proven_on_random_data(cuda, scan, k):
     D, I = idx.search(q, k)
     Dr, Ir = sr.search_exact(q, c, k)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
-    assert idx.last_fallback_queries <= (257 if scan == "f16" and k > 16 else 2 if k > 12 else 0)   # forced f16 at large k may fall back
+    assert idx.last_rescan_queries <= (257 if scan == "f16" and k > 16 else 2 if k > 12 else 0)   # forced f16 at large k may fall back
 
 
 def test_duplicates_tie_break_by_id(cuda, scan):
@@ -276,7 +276,7 @@ def test_large_corpus_matches_oracle_bit_exact(cuda, nq, n, scan):
     q, c = _unit(rng, nq, 128), _unit(rng, n, 128)
     idx = _index(c, cuda, scan=scan)
     D, I = _search_with_status(idx, q)
-    assert idx.last_fallback_queries == 0              # random data: every query proven exact on the fused path
+    assert idx.last_rescan_queries == 0              # random data: every query proven exact on the fused path
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
@@ -292,7 +292,7 @@ def test_large_sorted_adversarial_corpus(cuda, scan):
     D, I = _search_with_status(idx, q)
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
-    assert idx.last_fallback_queries <= 8               # at most the adversarial query (and unlucky near-ties)
+    assert idx.last_rescan_queries <= 8               # at most the adversarial query (and unlucky near-ties)
 
 
 def test_large_mass_duplicates(cuda, scan):
@@ -306,7 +306,9 @@ def test_large_mass_duplicates(cuda, scan):
     D, I = _search_with_status(idx, q)
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
-    assert idx.last_fallback_queries == 24
+    # 100 identical copies per row: the fused scan cannot prove any query; the threshold rung keeps all
+    # tied rows (a few hundred per query) and resolves them without the exhaustive kernels
+    assert idx.last_rescan_queries == 24 and idx.last_fallback_queries == 0
 
 
 def test_large_all_identical_rows(cuda, scan):
@@ -317,7 +319,8 @@ def test_large_all_identical_rows(cuda, scan):
     assert np.array_equal(I, np.tile(np.arange(10), (5, 1)))
     Dr, _ = sr.search_exact(q, c[:16], 10)
     assert np.array_equal(D, Dr)
-    assert idx.last_fallback_queries == 5
+    # 280k identical rows: more tied rows than the rung keeps -> the exhaustive kernels decide
+    assert idx.last_rescan_queries == 5 and idx.last_fallback_queries == 5
 
 
 def test_config_c4_10m_rows(cuda):
@@ -344,7 +347,8 @@ def test_config_c4_10m_rows(cuda):
     # the exact fallback -- the answer must not change
     idx = FlatIndex(d, "ip", cuda).adopt(c)
     D3, I3 = idx.search_device(q, k)
-    assert idx.last_scan == "f16" and idx.last_fallback_queries <= 8
+    assert idx.last_scan == "f16" and idx.last_rescan_queries <= 8
+    assert idx.last_fallback_queries == 0              # ... resolved by the threshold rung: no exhaustive pass at all
     assert torch.equal(I3, I) and torch.equal(D3, D)
     Dn, In = D.cpu().numpy(), I.cpu().numpy()
     assert (np.diff(Dn, axis=1) <= 0).all() and (In >= 0).all() and (In < n).all()
@@ -355,7 +359,7 @@ def test_config_c4_10m_rows(cuda):
         lo, hi = s * n // 8, (s + 1) * n // 8
         sh = FlatIndex(d, "ip", cuda).adopt(c[lo:hi], id_offset=lo)
         d_s, i_s = sh.search_device(q, k)                 # default scan (f16) + exact fallback for unproven queries
-        assert sh.last_fallback_queries <= 8
+        assert sh.last_rescan_queries <= 8 and sh.last_fallback_queries == 0
         Ds.append(d_s.clone()); Is.append(i_s.clone())
     Din, Iin = torch.stack(Ds).contiguous(), torch.stack(Is).contiguous()
     Dm, Im = torch.empty_like(D), torch.empty_like(I)
@@ -402,7 +406,7 @@ def test_split_scan_near_ties_inside_its_error_bound(cuda):
     D, I = idx.search(q, 10)
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
-    assert idx.last_fallback_queries > 0
+    assert idx.last_rescan_queries > 0 and idx.last_fallback_queries == 0     # near ties: the rung's job
     # the f32 scan resolves these scores: same answer
     D2, I2 = _index(c, cuda, scan="f32").search(q, 10)
     assert np.array_equal(I2, Ir) and np.array_equal(D2, Dr)
@@ -441,7 +445,7 @@ def test_f16_scan_on_unnormalised_vectors(cuda, scale):
     assert idx.last_scan == "f16"
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
-    assert idx.last_fallback_queries <= 20
+    assert idx.last_rescan_queries <= 20
 
 
 def test_f16_image_rescales_when_larger_rows_arrive(cuda):
@@ -463,7 +467,7 @@ def test_f16_image_rescales_when_larger_rows_arrive(cuda):
 
 def test_f16_scan_near_ties_inside_its_error_bound(cuda):
     """Clusters whose scores differ by ~1e-5: resolved by the f32 rows, invisible to one f16 pass
-    (bound ~1e-3 |q||c|).  The proof must send them to the exact fallback; the answer is the oracle's."""
+    (bound ~1e-3 |q||c|).  The proof must notice, the threshold rung resolves them; the answer is the oracle's."""
     rng = np.random.default_rng(75)
     base = _unit(rng, 1500, 128)
     c = np.repeat(base, 40, axis=0) + (rng.standard_normal((60000, 128)) * 2e-5).astype(np.float32)
@@ -473,7 +477,7 @@ def test_f16_scan_near_ties_inside_its_error_bound(cuda):
     D, I = idx.search(q, 10)
     Dr, Ir = sr.search_exact(q, c, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
-    assert idx.last_fallback_queries > 0
+    assert idx.last_rescan_queries > 0 and idx.last_fallback_queries == 0
 
 
 # ----------------------------------------------------------------------------------------------
@@ -507,7 +511,7 @@ def test_bf16_fused_matches_oracle_on_rounded_vectors(cuda, nq, n, d, k):
     idx = FlatIndex(d, "ip", cuda, dtype="bf16")
     idx.add(c)
     D, I = idx.search(q, k)
-    assert idx.last_fallback_queries <= nq // 50           # random data: (nearly) everything proven on the fused path
+    assert idx.last_rescan_queries <= nq // 50           # random data: (nearly) everything proven on the fused path
     Dr, Ir = sr.search_exact(_bf16_round(q), _bf16_round(c), k)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
@@ -541,7 +545,7 @@ def test_large_k_500_matches_oracle(cuda, scan):
     Dr, Ir = sr.search_exact(q, c, 500)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
     if scan != "f16":          # (forced f16 at k = 500: neighbouring scores lie inside its bound, most queries fall back;
-        assert idx.last_fallback_queries <= 64          # scan="auto" uses the split scan there)
+        assert idx.last_rescan_queries <= 64          # scan="auto" uses the split scan there)
 
 
 def test_auto_scan_picks_by_k_and_shape(cuda):
@@ -576,11 +580,99 @@ def test_auto_scan_escalates_on_a_near_duplicate_corpus(cuda):
     idx.add(c)
     Dr, Ir = sr.search_exact(q, c, 10)
     D, I = idx.search(q, 10)
-    assert idx.last_scan == "f16" and idx.last_fallback_queries > 5
+    assert idx.last_scan == "f16" and idx.last_rescan_queries > 5
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
     D, I = idx.search(q, 10)
     assert idx.last_scan == "split"
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_auto_scan_never_falls_off_the_ladder(cuda):
+    """d = 512: only the f16 image has a fused kernel (split / f32 rows would be 2048 bytes).  A batch full of
+    near ties must not demote the k class to a scan that does not exist (= every later query exhaustive)."""
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(78)
+    base = _unit(rng, 300, 512)
+    c = np.repeat(base, 40, axis=0) + (rng.standard_normal((12000, 512)) * 1e-5).astype(np.float32)
+    c = np.ascontiguousarray(c[rng.permutation(12000)]).astype(np.float32)
+    q = _unit(rng, 64, 512)
+    idx = FlatIndex(512, "ip", cuda)
+    idx.add(c)
+    Dr, Ir = sr.search_exact(q, c, 10)
+    for _ in range(3):
+        D, I = idx.search(q, 10)
+        assert idx.last_scan == "f16" and idx.last_rescan_queries > 5 and idx.last_fallback_queries == 0
+        assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_auto_scan_steps_back_down_after_clean_searches(cuda):
+    from sessionsimilaritysearch_amd import index as ix
+    rng = np.random.default_rng(79)
+    base = _unit(rng, 1500, 128)
+    c = np.repeat(base, 40, axis=0) + (rng.standard_normal((60000, 128)) * 2e-5).astype(np.float32)
+    c = np.ascontiguousarray(c[rng.permutation(60000)]).astype(np.float32)
+    idx = ix.FlatIndex(128, "ip", cuda)
+    idx.add(c)
+    idx.search(_unit(rng, 96, 128), 10)
+    assert idx.scan_for(10) == "split"                      # escalated by the near-duplicate batch
+    far = torch.from_numpy(_unit(rng, 64, 128)).to(cuda)
+    idx2 = ix.FlatIndex(128, "ip", cuda)
+    idx2.add(_unit(rng, 20000, 128))
+    idx2._auto_level[0] = 1                                 # as if escalated; random data is clean under any scan
+    for i in range(ix.AUTO_DECAY_SEARCHES):
+        assert idx2.scan_for(10) == "split"
+        idx2.search_device(far, 10)
+    assert idx2.scan_for(10) == "f16"
+    idx.add(c[:10])                                         # a changed corpus starts from the default again
+    assert idx.scan_for(10) == "f16"
+
+
+@pytest.mark.parametrize("scan_mode,d", [("f16", 128), ("split", 128), ("f32", 128), ("f16", 512), ("split", 64), ("f32", 256)])
+@pytest.mark.parametrize("k", [10, 100])
+def test_threshold_rung_resolves_every_query_by_itself(cuda, scan_mode, d, k):
+    """sss_ip_topk_threshold on ALL queries of a batch, starting from a deliberately poor lower bound (the k-th
+    best of a random 3 % sample of the corpus) -- thousands of rows pass the threshold for some queries: every
+    instantiation of the threshold form of k_scan, k_thr_prepare's thresholds and k_select_all's sort."""
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(d + k)
+    n, nq = 70001, 300
+    q, c = _unit(rng, nq, d), _unit(rng, n, d)
+    idx = FlatIndex(d, "ip", cuda, scan=scan_mode)
+    idx.add(c)
+    Dr, Ir = sr.search_exact(q, c, k)
+    sample = np.sort(rng.choice(n, n // 30, replace=False))
+    Ds, _ = sr.search_exact(q, c[sample], k)
+    tq = torch.from_numpy(q).to(cuda)
+    D = torch.from_numpy(Ds).to(cuda).contiguous()           # column k-1: a valid (loose) lower bound of the k-th score
+    I = torch.full((nq, k), -7, dtype=torch.int64, device=cuda)
+    status = torch.ones(nq, dtype=torch.int32, device=cuda)
+    left = idx.search_threshold(tq, k, D, I, status, torch.arange(nq, device=cuda))
+    assert idx.rung_scan() == scan_mode
+    done = (status == 0).cpu().numpy()
+    assert done.sum() >= nq * 0.5 and left.numel() == nq - done.sum()      # the rest overflowed the capacity: untouched
+    assert np.array_equal(I.cpu().numpy()[done], Ir[done]) and np.array_equal(D.cpu().numpy()[done], Dr[done])
+    assert (I.cpu().numpy()[~done] == -7).all()
+
+
+def test_threshold_rung_on_a_bf16_index_and_with_id_offset(cuda):
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(90)
+    n, nq, d, k = 50000, 200, 256, 10
+    q, c = _bf16_round(_unit(rng, nq, d)), _bf16_round(_unit(rng, n, d))
+    idx = FlatIndex(d, "ip", cuda, dtype="bf16")
+    idx.add(c)
+    idx.id_offset = 1_000_000
+    Dr, Ir = sr.search_exact(q, c, k, id_offset=1_000_000)
+    tq = idx._rows(q, "q")
+    D = torch.from_numpy(Dr - 2e-3).to(cuda).contiguous()
+    I = torch.zeros((nq, k), dtype=torch.int64, device=cuda)
+    status = torch.full((nq,), 4, dtype=torch.int32, device=cuda)
+    left = idx.search_threshold(tq, k, D, I, status, torch.arange(0, nq, 2, device=cuda))     # every other query
+    assert left.numel() == 0 and idx.rung_scan() == "native"
+    st = status.cpu().numpy()
+    assert (st[0::2] == 0).all() and (st[1::2] == 4).all()
+    assert np.array_equal(I.cpu().numpy()[0::2], Ir[0::2]) and np.array_equal(D.cpu().numpy()[0::2], Dr[0::2])
+    assert (I.cpu().numpy()[1::2] == 0).all()
 
 
 def test_index_add_in_pieces_equals_single_add(cuda):
