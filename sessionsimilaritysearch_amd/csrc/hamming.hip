@@ -23,9 +23,14 @@ constexpr int HSEL_THREADS = 256;
 
 template <int N>
 __device__ __forceinline__ void hlist_insert(unsigned (&ld)[N], int (&li)[N], unsigned d, int id) {
+    // ascending by distance; '<' puts the new row AFTER the entries it ties with (they came earlier = lower ids);
+    // from there on every entry moves down one place -- unconditionally: comparing the carried entry again
+    // would let it jump over the entries IT ties with and scramble the id order inside a tie
+    bool ins = false;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {                   // ascending by distance; '<' keeps earlier (= lower) ids first on ties
-        const bool c = d < ld[i];
+    for (int i = 0; i < N; ++i) {
+        const bool c = ins || d < ld[i];
+        ins = c;
         const unsigned nd = c ? d : ld[i];
         const int ni = c ? id : li[i];
         d = c ? ld[i] : d;

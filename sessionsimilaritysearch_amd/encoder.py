@@ -336,10 +336,13 @@ class SessionEncoder:
         err = torch.empty(1, dtype=torch.int32, device=dev)
         _lib.check(L.sss_graph_counts(sess_ptr.data_ptr(), is_search.data_ptr(), item_id.data_ptr(), S_, bases.data_ptr(),
                                       scratch.data_ptr(), err.data_ptr(), st), "sss_graph_counts")
-        tot = torch.cat([bases[:, S_], err]).tolist()              # the one host read-back of the build
-        Nq, Np, Xp, E, Epp, bad = (int(v) for v in tot)
+        lows = torch.stack([item_id.min(), query_tok.min()]).to(torch.int32) if item_id.numel() else bases.new_zeros(2)
+        tot = torch.cat([bases[:, S_], err, lows]).tolist()        # the one host read-back of the build
+        Nq, Np, Xp, E, Epp, bad, item_lo, tok_lo = (int(v) for v in tot)
         if bad:
             raise _lib.SssError("prepare_actions: a session has more than 64 actions")
+        if item_lo < 0 or tok_lo < 0:
+            raise IndexError("index out of range in self")         # negative ids: what nn.Embedding raises upstream
         i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
         i64 = lambda n: torch.empty(n, dtype=torch.int64, device=dev)
         pb = PreparedBatch()

@@ -721,6 +721,22 @@ def test_hamming_search_matches_oracle(cuda, nq, n, nbits, k):
     assert D.dtype == np.int32 and np.array_equal(D, Dr) and np.array_equal(I, Ir)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_hamming_short_codes_tie_order_inside_the_lists(cuda, seed):
+    """16- and 24-bit codes over a few hundred rows: more rows tie at the k-th distance than a per-thread list
+    holds, so the id order INSIDE a tie decides which rows a list keeps (a carried entry once jumped over the
+    entries it tied with: lower ids were evicted first and the proof did not notice)."""
+    from sessionsimilaritysearch_amd.index import BinaryFlatIndex
+    rng = np.random.default_rng(seed)
+    for nb, n, nq in ((2, 300, 10), (3, 600, 100), (2, 5000, 300), (1, 900, 40)):
+        codes = rng.integers(0, 256, (n + nq, nb), dtype=np.uint8)
+        idx = BinaryFlatIndex(nb * 8, cuda)
+        idx.add(codes[nq:])
+        D, I = idx.search(codes[:nq], 10)
+        Dr, Ir = sr.hamming_search(codes[:nq], codes[nq:], 10)
+        assert np.array_equal(I, Ir) and np.array_equal(D, Dr), (nb, n, nq)
+
+
 def test_hamming_massive_ties(cuda):
     """Few distinct codes -> thousands of rows tie at every distance; ids must come out ascending."""
     from sessionsimilaritysearch_amd.index import BinaryFlatIndex
