@@ -39,48 +39,9 @@
 //   * at the end each lane appends its real entries to the query's compact candidate array
 //     (one atomic add per lane) for k_select_* (select.hip).
 #include "scan.h"
+#include "scan_dev.h"
 
 namespace sss {
-
-typedef char __attribute__((address_space(3)))* lptr_c;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// Sorted (descending) insert of (x, id) into a register list; lanes whose x does not beat
-// their list tail fall through untouched.
-template <int N>
-__device__ __forceinline__ void list_insert(float (&ls)[N], int (&li)[N], float x, int id) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const bool c = x > ls[i];
-        const float ns = c ? x : ls[i];
-        const int ni = c ? id : li[i];
-        x = c ? ls[i] : x;
-        id = c ? li[i] : id;
-        ls[i] = ns;
-        li[i] = ni;
-    }
-}
-
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// Two 16-byte agent-scope (sc1: not served from this CU's L1) loads + their wait, as ONE asm
-// statement so the destinations are never touched before the data has landed.
-__device__ __forceinline__ unsigned min8_sc1(const unsigned* p) {
-    u32x4 a, b;
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
-                 "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
-    const unsigned m0 = min(min(a.x, a.y), min(a.z, a.w));
-    const unsigned m1 = min(min(b.x, b.y), min(b.z, b.w));
-    return min(m0, m1);
-}
 
 // NW = waves per workgroup: 8 (two per SIMD, 256 VGPRs each) or, for 1024-byte rows whose resident
 // queries alone take 128 VGPRs, 4 (one per SIMD, 512 VGPRs: no spills; NW * 32 queries per workgroup).
@@ -124,60 +85,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     int q_ld = q_glob < nq ? q_glob : nq - 1;
     if constexpr (THR) q_ld = A.qsel[q_ld];             // row of Q this lane's (compact) query lives in
     f32x4 qc[NU];
-    if constexpr (DT == DT_SPLIT) {
-        // f32 queries, split here: qc[u] = hi and qc[u + NU/2] = lo of k-slice u (k = 16u + 8h .. + 7),
-        // the B operands that meet chunk 2u + h of the hi half / of the lo half of a corpus row.
-        const f32x4* qp = reinterpret_cast<const f32x4*>(Qb + (size_t)q_ld * RB) + 2 * h;
-#pragma unroll
-        for (int u = 0; u < NU / 2; ++u) {
-            const f32x4 a = qp[4 * u], b = qp[4 * u + 1];
-            const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-            bf16x8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                hi[e] = (__bf16)x[e];
-                const float rem = x[e] - (float)hi[e];
-                lo[e] = (__bf16)(__builtin_isfinite(rem) ? rem : 0.f);
-            }
-            qc[u] = __builtin_bit_cast(f32x4, hi);
-            qc[u + NU / 2] = __builtin_bit_cast(f32x4, lo);
-        }
-#pragma unroll
-        for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(qc[u]));
-    } else if constexpr (DT == DT_F16) {
-        // f32 queries (4 * (RB / 2) bytes per row), scaled by the query's own power of two (scan.h:
-        // f16_shift of its largest |element|) and rounded to f16: qc[u] = k-slice u (k = 16u + 8h .. + 7).
-        const f32x4* qp = reinterpret_cast<const f32x4*>(Qb + (size_t)q_ld * (2 * RB)) + 2 * h;
-        f32x4 raw[2 * NU];
-        float amax = 0.f;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) { raw[2 * u] = qp[4 * u]; raw[2 * u + 1] = qp[4 * u + 1]; }
-#pragma unroll
-        for (int u = 0; u < 2 * NU; ++u)
-            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(raw[u].x), fabsf(raw[u].y))), fmaxf(fabsf(raw[u].z), fabsf(raw[u].w)));
-        amax = fmaxf(amax, __shfl_xor(amax, 32));            // the other half of the row
-        const int sh = f16_shift(amax);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const f32x4 a = raw[2 * u], b = raw[2 * u + 1];
-            f16x8 v;
-            v[0] = (_Float16)ldexpf(a.x, sh); v[1] = (_Float16)ldexpf(a.y, sh);
-            v[2] = (_Float16)ldexpf(a.z, sh); v[3] = (_Float16)ldexpf(a.w, sh);
-            v[4] = (_Float16)ldexpf(b.x, sh); v[5] = (_Float16)ldexpf(b.y, sh);
-            v[6] = (_Float16)ldexpf(b.z, sh); v[7] = (_Float16)ldexpf(b.w, sh);
-            qc[u] = __builtin_bit_cast(f32x4, v);
-        }
-#pragma unroll
-        for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(qc[u]));
-    } else {
-        const f32x4* qp = reinterpret_cast<const f32x4*>(Qb + (size_t)q_ld * RB) + h;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) qc[u] = qp[2 * u];
-        // retire the query loads HERE: otherwise hipcc sinks their counted vmcnt waits into the
-        // tile loop, where they would also wait on the (uncounted) LDS-DMA of the next tile.
-#pragma unroll
-        for (int u = 0; u < NU; ++u) asm volatile("" : "+v"(qc[u]));
-    }
+    load_queries<RB, DT>(Qb, q_ld, h, qc);
 
     // Lane list, sorted descending; empty slots are (-inf, -1).  thr = max(list tail, tau) is the
     // one value the hot path compares against.
