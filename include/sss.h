@@ -129,6 +129,24 @@ int sss_ip_topk_threshold(const void* q, const int32_t* qsel, int64_t nsel, cons
                           int d, int k, int64_t id_offset, float corpus_max_norm, float* D_out, int64_t* I_out,
                           int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
+/* LONG rows (the reference's own D = 1600 session vectors, K = 100: pretrain_filtered_amazon.py:281,
+ * test_amazon_filterd.py:459,578 -- `index.search(normalize(emb), K)`): any d % 64 == 0 up to 8192, k <= 4096.
+ * A K-tiled MFMA contraction (256 queries x 256 rows per workgroup tile, both operands streamed through LDS in
+ * 128-byte slabs) whose top-k rides on thresholds instead of running lists: a few evenly spread row samples of
+ * growing size give, level by level, a tighter lower bound of each query's k-th score; the last pass over every
+ * row keeps exactly the rows that can still reach that bound and re-scores them all canonically (float64, from
+ * `corpus`).  status 0 = exact; 1 = more than 8192 rows could reach the bound (mass ties): re-run through
+ * sss_ip_topk_exhaustive(_lb) -- column k-1 of such a row of D_out still holds a valid lower bound (or -FLT_MAX).
+ * dtype 0: q / corpus float32, scan_image = the scaled float16 image of the corpus (sss_scale_f16; corpus_shift /
+ * corpus_resid_norm as for sss_ip_topk_f16; the queries are scaled + rounded to float16 internally).
+ * dtype 1: q / corpus bfloat16, scan_image = corpus (shift / residual ignored).
+ * workspace (256-byte aligned): sss_ip_topk_long_workspace_bytes(nq, n, d, dtype). */
+size_t sss_ip_topk_long_workspace_bytes(int64_t nq, int64_t n, int d, int dtype);
+int sss_ip_topk_long(const void* q, int64_t nq, const void* corpus, int dtype, const void* scan_image,
+                     int corpus_shift, float corpus_resid_norm, int64_t n, int d, int k, int64_t id_offset,
+                     float corpus_max_norm, float* D_out, int64_t* I_out, int32_t* status, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* Exhaustive exact search for a (small) set of queries: qsel [nsel] int32 are the query rows of
  * q to process; results are written to rows qsel[i] of D_out / I_out.  Any n, any d % 4 == 0
  * (dtype 0) or d % 8 == 0 (dtype 1), k <= 1024.  metric: 0 = inner product, 1 = squared L2

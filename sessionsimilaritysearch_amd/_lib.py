@@ -39,6 +39,9 @@ _SIGNATURES = {
     "sss_ip_topk_f16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_float, c_int64, c_int, c_int, c_int64, c_float,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t,
                                 c_void_p]),
+    "sss_ip_topk_long_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "sss_ip_topk_long": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_float, c_int64, c_int, c_int, c_int64,
+                                 c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sss_ip_topk_threshold_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
     "sss_ip_topk_threshold": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_int64,
                                       c_int, c_int, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

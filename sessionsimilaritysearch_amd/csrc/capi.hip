@@ -39,6 +39,9 @@ int ip_topk_f16(const float*, long, const float*, const void*, int, float, long,
                 void*, size_t, void*, size_t, hipStream_t);
 int f16_resid_max(const float*, const unsigned short*, long, int, int, float*, hipStream_t);
 size_t ip_topk_scan_workspace_bytes(long, long, int, int, int);
+size_t ip_topk_long_workspace_bytes(long, long, int, int);
+int ip_topk_long(const void*, long, const void*, int, const void*, int, float, long, int, int, long, float, float*, long*, int*, void*,
+                 size_t, hipStream_t);
 size_t ip_topk_threshold_workspace_bytes(long, long, int, int);
 int ip_topk_threshold(const void*, const int*, long, const void*, int, const void*, int, int, float, long, int, int, long, float,
                       float*, long*, int*, void*, size_t, hipStream_t);
@@ -147,6 +150,17 @@ int sss_ip_topk_f16(const float* q, int64_t nq, const float* corpus, const uint1
     return sss::ip_topk_f16(q, nq, corpus, corpus_f16, corpus_shift, corpus_resid_norm, n, d, k, id_offset, corpus_max_norm, D_out,
                             reinterpret_cast<long*>(I_out), status, unproven_count, state, state_bytes, workspace,
                             workspace_bytes, ST(stream));
+}
+size_t sss_ip_topk_long_workspace_bytes(int64_t nq, int64_t n, int d, int dtype) {
+    return sss::ip_topk_long_workspace_bytes(nq, n, d, dtype);
+}
+int sss_ip_topk_long(const void* q, int64_t nq, const void* corpus, int dtype, const void* scan_image, int corpus_shift,
+                     float corpus_resid_norm, int64_t n, int d, int k, int64_t id_offset, float corpus_max_norm, float* D_out,
+                     int64_t* I_out, int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+    if (dtype != 0 && dtype != 1) { sss::set_error("ip_topk_long: dtype must be 0 (f32) or 1 (bf16)"); return SSS_EINVAL; }
+    return sss::ip_topk_long(q, nq, corpus, dtype, scan_image, corpus_shift, corpus_resid_norm, n, d, k, id_offset,
+                             corpus_max_norm, D_out, reinterpret_cast<long*>(I_out), status, workspace, workspace_bytes,
+                             ST(stream));
 }
 size_t sss_ip_topk_threshold_workspace_bytes(int64_t nsel, int64_t n, int d, int scan) {
     return sss::ip_topk_threshold_workspace_bytes(nsel, n, d, scan);

@@ -1,0 +1,280 @@
+// Scoring + top-k for LONG rows -- the reference's own session vectors are D = 1600 wide with K = 100
+// (pretrain_filtered_amazon.py:281, test_amazon_filterd.py:459,578: `index.search(normalize(emb), K)`), far beyond
+// the 1024-byte rows k_scan keeps resident in registers.  gfx950 / CDNA4.
+//
+// A row of 3200 bytes (f16 image of a float32 index) or more fits neither the registers nor LDS next to a query
+// tile, so the scan is a K-TILED contraction: k_scan_long = 256 queries x 256 corpus rows per workgroup tile,
+// both operands streamed through LDS in 128-byte K slabs (LDS-DMA, double buffered, XOR swizzle on the source
+// address), v_mfma_f32_32x32x16_{f16,bf16} accumulating the full dot products in 8 accumulators per wave
+// (a wave = 32 queries x 256 rows; a lane owns one query column, exactly as in k_scan).
+//
+// The top-k rides on the THRESHOLD machinery of the rung (select.hip: THRESHOLD RUNG) instead of running lists:
+// the epilogue of a tile only compares its 128 scores per lane with the lane's fixed threshold and appends what
+// passes.  The threshold comes from LEVELS of evenly spread row samples:
+//   level 1   a few tiles (<= 4096 rows), threshold -inf: every sampled row is kept, k_select_all re-scores them
+//             canonically (float64) -> the exact top-k of the sample, whose k-th score is a valid LOWER BOUND of the
+//             true k-th score;
+//   level i   a sample `factor` times larger scanned with threshold = (bound - scan error bound - one ulp):
+//             about k * factor rows pass per query, all re-scored -> the exact top-k of that sample, a tighter bound;
+//   last      every row.  What passes is everything that can still reach the k-th score already known -- near ties
+//             and duplicate rows included -- so the canonical re-score of all of it IS the exact answer
+//             (status 0); a query with more than 8192 such rows keeps status 1 and goes to the exhaustive kernels.
+// Two to three passes, the last one dominant; no per-lane list, no shared threshold slots, no bootstrap.
+#include "scan.h"
+#include "scan_dev.h"
+
+namespace sss {
+
+constexpr int LT_ROWS = 256;        // corpus rows per workgroup tile
+constexpr int LT_Q = 256;           // queries per workgroup (8 waves x 32)
+constexpr int LT_BK = 128;          // bytes of K per slab (64 16-bit elements = 4 MFMA k-groups)
+constexpr int LT_STAGE = (LT_ROWS + LT_Q) * LT_BK;     // 64 KB: one slab of both operands
+
+struct LongArgs {
+    const void* Qimg;               // [nq][d] 16-bit queries (f16: scaled image, bf16: the queries themselves)
+    const void* C;                  // [n][d] 16-bit rows (f16 image / bf16 rows)
+    int nq, n, d, G, S;
+    int tile_count;                 // tiles this level scans: tile j of the level = corpus tile j * total_tiles / tile_count
+    int total_tiles, tiles_per_split, cap;
+    const float* thr;               // [nq] per-query threshold in the scan's domain
+    unsigned* cnt;                  // [nq] rows kept so far
+    unsigned long long* cand;       // [nq][cap]
+};
+
+// f32 queries -> f16 image scaled by the query's own power of two (scan.h: f16_shift of its largest |element|) --
+// what k_scan's prologue does in registers; the select side (err_bound / k_thr_prepare) re-derives the same shift.
+__global__ __launch_bounds__(256) void k_query_f16(const float* __restrict__ q, int nq, int d, _Float16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nq) return;
+    const float* row = q + (size_t)i * d;
+    float amax = 0.f;
+    for (int kk = lane; kk < d; kk += 64) amax = fmaxf(amax, fabsf(row[kk]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const int sh = f16_shift(amax);
+    for (int kk = lane; kk < d; kk += 64) out[(size_t)i * d + kk] = (_Float16)ldexpf(row[kk], sh);
+}
+
+template <int DT>
+__global__ __launch_bounds__(512, 2) void k_scan_long(const LongArgs A) {
+    static_assert(DT == DT_F16 || DT == DT_BF16, "16-bit rows");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nq = A.nq, n = A.n, S = A.S, G = A.G;
+    const int rb = A.d * 2;                             // bytes per row (queries and corpus alike)
+    const int nslab = rb / LT_BK;
+    const char* __restrict__ Qb = reinterpret_cast<const char*>(A.Qimg);
+    const char* __restrict__ Cb = reinterpret_cast<const char*>(A.C);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware remap (as k_scan): the G query groups that stream one split sit on ONE XCD.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int split = xcd * (S >> 3) + slot / G;
+    const int g = slot % G;
+    int j_lo = split * A.tiles_per_split, j_hi = j_lo + A.tiles_per_split;
+    if (j_hi > A.tile_count) j_hi = A.tile_count;
+    if (j_lo >= j_hi) return;                           // whole workgroup: no barrier below is skipped by part of it
+
+    const int q_glob = g * LT_Q + wave * 32 + r;
+    const float thr = q_glob < nq ? A.thr[q_glob] : INFINITY;   // padding lanes never keep anything
+
+    // ---- staging: a slab is [256 rows][128 B] of the corpus tile followed by [256 queries][128 B]; 1 KiB pieces
+    // (8 rows x 8 chunks); chunk c of row t sits at chunk slot c ^ ((t >> 1) & 7): with 128-byte rows two rows share
+    // a 256-byte bank row, and this key makes every 16-lane group of a ds_read_b128 (16 consecutive rows, one chunk)
+    // cover all 64 banks exactly once.
+    const unsigned lds_base = (unsigned)(unsigned long)(lptr_c)smem;
+    const long q_row0 = (long)g * LT_Q;
+    auto stage = [&](int buf, int tile, int slab) __attribute__((always_inline)) {
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        slab = __builtin_amdgcn_readfirstlane(slab);
+        const long c_row0 = (long)tile * LT_ROWS;
+        // 64 pieces per slab: 0..31 corpus rows, 32..63 queries; wave w takes pieces w, w + 8, ...
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = wave + 8 * i;                         // wave-uniform
+            const bool is_q = p >= 32;
+            const int t = ((p & 31) << 3) + (lane >> 3);        // row of the (corpus | query) tile
+            const int c = (lane & 7) ^ ((t >> 1) & 7);
+            long row = (is_q ? q_row0 : c_row0) + t;
+            const long last = (is_q ? (long)nq : (long)n) - 1;
+            if (row > last) row = last;                         // ragged tile / short query batch: clamp
+            const char* src = (is_q ? Qb : Cb) + (size_t)row * rb + (size_t)slab * LT_BK + c * 16;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * LT_STAGE + p * 1024);
+            // (per-lane 64-bit source address: rows are up to 6400 bytes apart, tiles up to gigabytes)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         : : "v"(src), "s"(dst) : "memory");
+        }
+    };
+
+    const f32x16 zero = {0};
+    f32x16 acc[8];
+    const int keyq = ((wave * 32 + r) >> 1) & 7;                // swizzle key of this lane's query row
+    const int total_steps = (j_hi - j_lo) * nslab;             // slab steps of this split
+    auto tile_of = [&](int j) __attribute__((always_inline)) { return (int)((long)j * A.total_tiles / A.tile_count); };
+
+    stage(0, tile_of(j_lo), 0);
+    int step = 0;
+    for (int j = j_lo; j < j_hi; ++j) {
+        const int tile = tile_of(j);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[b] = zero;
+        for (int s = 0; s < nslab; ++s, ++step) {
+            const int buf = step & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current slab have landed
+            __syncthreads();                                    // ... everyone's have, and the other buffer is free
+            if (step + 1 < total_steps) {
+                const bool next_tile = s + 1 == nslab;
+                stage(buf ^ 1, next_tile ? tile_of(j + 1) : tile, next_tile ? 0 : s + 1);
+            }
+            const char* rows = smem + buf * LT_STAGE;
+            const char* qs = rows + LT_ROWS * LT_BK;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cq = (2 * u + h) ^ keyq;
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(qs + (wave * 32 + r) * LT_BK + cq * 16);
+                f32x4 a[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int t = b * 32 + r;
+                    const int c = (2 * u + h) ^ ((t >> 1) & 7);
+                    a[b] = *reinterpret_cast<const f32x4*>(rows + t * LT_BK + c * 16);
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    if constexpr (DT == DT_F16)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[b]), __builtin_bit_cast(f16x8, bq), acc[b], 0, 0, 0);
+                    else
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[b]), __builtin_bit_cast(bf16x8, bq), acc[b], 0, 0, 0);
+                }
+            }
+        }
+        // ---- tile epilogue: acc[b][jj] is (corpus row tile * 256 + 32 b + (jj & 3) + 8 (jj >> 2) + 4 h, query r)
+        float m = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+#pragma unroll
+            for (int jj = 0; jj < 16; jj += 2) m = vmax3(m, acc[b][jj], acc[b][jj + 1]);
+        }
+        if (__builtin_amdgcn_ballot_w64(m > thr) != 0) {
+            const int row_base = tile * LT_ROWS + 4 * h;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int row = row_base + 32 * b + (jj & 3) + 8 * (jj >> 2);
+                    if (acc[b][jj] > thr && row < n) {
+                        const unsigned pos = atomicAdd(A.cnt + q_glob, 1u);
+                        if (pos < (unsigned)A.cap) A.cand[(size_t)q_glob * A.cap + pos] = make_key(acc[b][jj], row);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+constexpr int LONG_CAP = 8192;      // rows kept per query (k_select_all sorts them in 64 KB of LDS)
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static bool long_shape_ok(int d, int exact_dtype, int scan_dtype) {
+    if (d <= 0 || d % 64 || d > 8192) return false;
+    return (exact_dtype == DT_F32 && scan_dtype == DT_F16) || (exact_dtype == DT_BF16 && scan_dtype == DT_BF16);
+}
+
+size_t ip_topk_long_workspace_bytes(long nq, long n, int d, int dtype) {
+    const int scan = dtype == DT_F32 ? DT_F16 : DT_BF16;
+    if (nq <= 0 || n <= 0 || !long_shape_ok(d, dtype, scan)) return 0;
+    return al256((size_t)nq * d * 2) + al256((size_t)nq * 4) * 3 + (size_t)nq * LONG_CAP * 8;
+}
+
+int launch_thr_prepare(const ThrArgs& a, hipStream_t st);
+int launch_select_all(const ThrArgs& a, hipStream_t st);
+
+__global__ void k_iota(int* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, const void* c_scan, int corpus_shift,
+                 float corpus_resid, long n, int d, int k, long id_offset, float corpus_max_norm, float* D_out, long* I_out,
+                 int* status, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int scan_dtype = exact_dtype == DT_F32 ? DT_F16 : DT_BF16;
+    if (nq <= 0 || n <= 0 || k <= 0) { set_error("ip_topk_long: nq, n, k must be positive"); return SSS_EINVAL; }
+    if (!long_shape_ok(d, exact_dtype, scan_dtype)) { set_error("ip_topk_long: need dtype 0 / 1 and d %% 64 == 0, d <= 8192 (got dtype %d d %d)", exact_dtype, d); return SSS_EINVAL; }
+    if (!c_scan || (reinterpret_cast<uintptr_t>(c_scan) & 15)) { set_error("ip_topk_long: scan image missing or not 16-byte aligned"); return SSS_EINVAL; }
+    if (n >= (1L << 31) - 1024 || nq >= (1L << 31)) { set_error("ip_topk_long: n and nq must be < 2^31"); return SSS_EINVAL; }
+    if (2 * k > LONG_CAP) { set_error("ip_topk_long: k too large (max %d)", LONG_CAP / 2); return SSS_EINVAL; }
+    if (reinterpret_cast<uintptr_t>(ws) & 255) { set_error("ip_topk_long: workspace must be 256-byte aligned"); return SSS_EINVAL; }
+    const size_t need = ip_topk_long_workspace_bytes(nq, n, d, exact_dtype);
+    if (ws_bytes < need) { set_error("ip_topk_long: workspace %zu < %zu", ws_bytes, need); return SSS_EWORKSPACE; }
+    char* w = reinterpret_cast<char*>(ws);
+    void* qimg = w;                              w += al256((size_t)nq * d * 2);
+    int* qsel = reinterpret_cast<int*>(w);       w += al256((size_t)nq * 4);
+    float* thr = reinterpret_cast<float*>(w);    w += al256((size_t)nq * 4);
+    unsigned* cnt = reinterpret_cast<unsigned*>(w); w += al256((size_t)nq * 4);
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(w);
+
+    const void* q_scan = q;
+    if (scan_dtype == DT_F16) {
+        hipLaunchKernelGGL(k_query_f16, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const float*>(q), (int)nq, d,
+                           reinterpret_cast<_Float16*>(qimg));
+        q_scan = qimg;
+    }
+    hipLaunchKernelGGL(k_iota, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, qsel, (int)nq);
+    // "no bound known": column k-1 = -FLT_MAX makes k_thr_prepare hand out a -inf threshold
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(D_out), (int)0xFF7FFFFFu, (size_t)nq * k, st) != hipSuccess) { set_error("ip_topk_long: memset failed"); return SSS_EHIP; }
+    int rc = check_launch("k_query_f16 / k_iota");
+    if (rc) return rc;
+
+    // ---- levels: 16 tiles, then `factor` times more per level until every tile is scanned; about k * factor rows pass
+    // a level's threshold, so factor <= cap / (4 k) keeps a 2x margin below the capacity
+    const int total_tiles = (int)((n + LT_ROWS - 1) / LT_ROWS);
+    int fmax = LONG_CAP / (4 * k);
+    if (fmax < 2) fmax = 2;
+    int levels = 1;
+    for (double t = 16; t < total_tiles; t *= fmax) ++levels;
+    const double factor = levels > 1 ? pow((double)total_tiles / 16.0, 1.0 / (levels - 1)) : 1.0;
+
+    ThrArgs t;
+    t.Q = q; t.C = c_exact; t.qsel = qsel; t.nsel = (int)nq; t.d = d; t.dtype = exact_dtype; t.k = k; t.cap = LONG_CAP;
+    t.scan_dtype = scan_dtype; t.corpus_shift = corpus_shift; t.corpus_resid = corpus_resid; t.corpus_max_norm = corpus_max_norm;
+    t.id_offset = id_offset; t.thr = thr; t.cnt = cnt; t.cand = cand; t.D_out = D_out; t.I_out = I_out; t.status = status;
+    LongArgs a;
+    a.Qimg = q_scan; a.C = c_scan; a.nq = (int)nq; a.n = (int)n; a.d = d; a.G = (int)((nq + LT_Q - 1) / LT_Q);
+    a.total_tiles = total_tiles; a.cap = LONG_CAP; a.thr = thr; a.cnt = cnt; a.cand = cand;
+    static bool attr_done[MAX_DEVICES][2] = {};
+    const int dev = current_device();
+    for (int lv = 0; lv < levels; ++lv) {
+        int tiles = lv == levels - 1 ? total_tiles : (int)(16.0 * pow(factor, lv) + 0.5);
+        if (tiles > total_tiles) tiles = total_tiles;
+        a.tile_count = tiles;
+        int S = (256 / a.G) & ~7;
+        if (S < 8) S = 8;
+        while (S > 8 && S > tiles) S -= 8;
+        a.S = S;
+        a.tiles_per_split = (tiles + S - 1) / S;
+        t.n = (long)tiles * LT_ROWS < n ? (long)tiles * LT_ROWS : n;       // rows this level can see (k_select_all: "at least min(k, n) kept")
+        if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(status), 1, (size_t)nq, st) != hipSuccess) { set_error("ip_topk_long: memset failed"); return SSS_EHIP; }
+        rc = launch_thr_prepare(t, st);                                     // thresholds from column k-1 of D_out; counters zeroed
+        if (rc) return rc;
+        const size_t lds = 2 * (size_t)LT_STAGE;
+        const int ti = scan_dtype == DT_F16 ? 0 : 1;
+        if (!attr_done[dev][ti]) {
+            if (ti == 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_long<DT_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_long<DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done[dev][ti] = true;
+        }
+        if (ti == 0) hipLaunchKernelGGL(k_scan_long<DT_F16>, dim3(a.S * a.G), dim3(512), lds, st, a);
+        else hipLaunchKernelGGL(k_scan_long<DT_BF16>, dim3(a.S * a.G), dim3(512), lds, st, a);
+        rc = check_launch("k_scan_long");
+        if (rc) return rc;
+        rc = launch_select_all(t, st);
+        if (rc) return rc;
+    }
+    return SSS_OK;
+}
+
+}  // namespace sss

@@ -33,6 +33,8 @@ AUTO_ESCALATE = 0.005
 AUTO_DECAY_SEARCHES = 64        # clean searches at an escalated level before the class steps back down one scan
 _LADDER = ("f16", "split", "f32")
 FUSED_MAX_K = 500
+LONG_MAX_K = 4096                                                # sss_ip_topk_long: k <= capacity / 2
+LONG_MAX_D = 8192
 DTYPE_CODE = {"f32": 0, "bf16": 1}                               # include/sss.h: dtype
 _EXHAUSTIVE_WS_BYTES = 1 << 30
 
@@ -189,10 +191,15 @@ class FlatIndex:
 
     def scan_for(self, k: int) -> str:
         """Which candidate scan a fused search for k results uses ("" = none: exhaustive path)."""
-        if self.metric != "ip" or not (0 < k <= FUSED_MAX_K) or self.ntotal == 0:
+        if self.metric != "ip" or k <= 0 or self.ntotal == 0:
+            return ""
+        fused_shape = self.d in FUSED_DIMS[self.dtype] or (self.dtype == "f32" and self.d in F16_SCAN_DIMS)
+        if not fused_shape:
+            return self._long_or_none(k)         # rows longer than the register-resident scans take (D = 1600 ...)
+        if k > FUSED_MAX_K:
             return ""
         if self.dtype != "f32":
-            return "native" if self.d in FUSED_DIMS[self.dtype] else ""
+            return "native"
         want = self.scan
         if want == "auto":
             level = max(self._k_class(k), self._auto_level.get(self._k_class(k), 0))
@@ -204,6 +211,10 @@ class FlatIndex:
         if want == "f16" and not self._scan_served("f16"):
             want = "split"
         return want if self._scan_served(want) else ""
+
+    def _long_or_none(self, k: int) -> str:
+        """"long": the K-tiled scan for rows beyond the register-resident kernels (``sss_ip_topk_long``)."""
+        return "long" if (self.d % 64 == 0 and self.d <= LONG_MAX_D and k <= LONG_MAX_K) else ""
 
     def _scan_served(self, scan: str) -> bool:
         """Does a fused kernel exist for this scan at this d?"""
@@ -289,7 +300,7 @@ class FlatIndex:
         """Build whatever a fused search for k results needs (images, norms) now rather than on
         the first search; returns the scan that will be used."""
         mode = self.scan_for(k)
-        if mode == "f16":
+        if mode == "f16" or (mode == "long" and self.dtype == "f32"):
             self._ensure_f16()
             self.corpus_resid_norm()
         elif mode == "split":
@@ -365,6 +376,17 @@ class FlatIndex:
         mode = self.last_scan = self.prepare(k)
         if mode == "":
             raise _lib.SssError("search_fused: this index / k has no fused path (use search)")
+        if mode == "long":
+            ws = self._workspace(L.sss_ip_topk_long_workspace_bytes(nq, n, self.d, DTYPE_CODE[self.dtype]))
+            image = self._f16 if self.dtype == "f32" else self._xb
+            rc = L.sss_ip_topk_long(q.data_ptr(), nq, self._xb.data_ptr(), DTYPE_CODE[self.dtype], image.data_ptr(), self._c_shift,
+                                    self.corpus_resid_norm() if self.dtype == "f32" else 0.0, n, self.d, k, self.id_offset,
+                                    self.corpus_max_norm(), D.data_ptr(), I.data_ptr(), status.data_ptr(), ws.data_ptr(),
+                                    ws.numel(), _lib.stream_ptr(self.device))
+            _lib.check(rc, "sss_ip_topk_long")
+            if unproven_count is not None:
+                unproven_count += (status != 0).sum().to(torch.int32)
+            return D, I, status
         if mode == "f16":
             nbytes = L.sss_ip_topk_f16_workspace_bytes(nq, n, self.d, k)
         else:
@@ -398,6 +420,8 @@ class FlatIndex:
             return ""
         if self.dtype != "f32":
             return "native" if self.d in FUSED_DIMS[self.dtype] else ""
+        if not any(self._scan_served(s) for s in _LADDER):
+            return ""                            # long rows: their scan IS a threshold scan; what it leaves is mass ties
         if self.scan in ("auto", "f16") and self._scan_served("f16"):
             return "f16"
         if self.scan == "split" and self._scan_served("split"):

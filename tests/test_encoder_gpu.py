@@ -149,6 +149,29 @@ def test_encoder_matches_oracle(cuda, d, layers, n, loops, fused):
     assert np.abs(gn - rn_).max() < TOL
 
 
+def test_encoder_at_the_reference_model_shapes(cuda):
+    """The deployed model's shapes: 768-wide node features (rows of random feature tables here -- the text encoder
+    that produces them upstream is out of scope), h = 800, 3 layers, node width 3168, session vector D = 1600,
+    batches of 200 sessions (pretrain_filtered_amazon.py:267,281; config.py:15-16,21; test_amazon_filterd.py:488)
+    -- against both oracles."""
+    cfg = EncoderConfig(d_in=768, h=800, n_layers=3, d_out=1600, n_items=3000, n_query=65)
+    w = init_weights(cfg, 20260800)
+    b = S.build_batch(S.synthetic_actions(200, 800, cfg.n_items, cfg.n_query))
+    enc = SessionEncoder(cfg, w, cuda)
+    got, nodes = enc(b.to(cuda), get_node=True)
+    bt = b.to_torch("cpu")
+    ref, rn = gnn_ref.encoder_forward(bt, w, cfg.n_layers, get_node=True)
+    ref64 = gnn_ref.encoder_forward(bt, w, cfg.n_layers, dtype=torch.float64)
+    assert got.shape == (200, 1600) and nodes["product"].shape[1] == 3168
+    scale = max(1.0, float(ref.abs().max()))
+    for t in ("query", "product"):
+        assert (nodes[t].cpu() - rn[t]).abs().max() < 5e-5 * max(1.0, float(rn[t].abs().max()))
+    assert (got.cpu() - ref).abs().max() < TOL * scale
+    e_got, e_ref = (got.cpu().double() - ref64).abs().max(), (ref.double() - ref64).abs().max()
+    assert e_got <= 4 * e_ref + 1e-6 * scale
+    assert np.abs(sr.normalize(got.cpu().numpy()) - sr.normalize(ref.numpy())).max() < TOL
+
+
 def test_encoder_wider_hidden_than_input_and_edge_cases(cuda):
     cfg = EncoderConfig(d_in=32, h=64, n_layers=2, d_out=96, n_items=300, n_query=33)
     # sessions with only searches (single "unknown item" node), single-click sessions, repeats

@@ -154,13 +154,58 @@ def test_small_corpus_large_k_uses_exhaustive_and_is_exact(cuda):
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
-def test_reference_dim_1600_goes_through_exhaustive(cuda):
-    """The reference's session vectors are D=1600 (pretrain_filtered_amazon.py:281)."""
-    rng = np.random.default_rng(8)
-    q, c = _unit(rng, 8, 1600), _unit(rng, 3000, 1600)
+@pytest.mark.parametrize("nq,n,d,k", [
+    (8, 3000, 1600, 100),         # one level (the whole corpus is the first sample)
+    (300, 100_000, 1600, 100),    # the reference's shape: D = 1600, K = 100 (pretrain_filtered_amazon.py:281, test_amazon_filterd.py:459)
+    (64, 70_001, 1600, 10),       # ragged last tile, small k (one big factor between the levels)
+    (33, 20_000, 320, 500),       # shortest long row (640-byte f16 rows), large k
+    (100, 30_000, 2048, 1),
+])
+def test_long_rows_take_the_k_tiled_scan(cuda, nq, n, d, k):
+    rng = np.random.default_rng(nq + n + d)
+    q, c = _unit(rng, nq, d), _unit(rng, n, d)
+    idx = _index(c, cuda)
+    D, I = idx.search(q, k)
+    assert idx.last_scan == "long" and idx.last_rescan_queries == 0      # every query proven by the scan itself
+    Dr, Ir = sr.search_exact(q, c, k)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_long_rows_duplicates_ties_and_sorted_corpus(cuda):
+    """Duplicate rows tie exactly (ascending id decides), a corpus sorted by score for one query, and a query with
+    more tied rows than the scan keeps (-> status 1 -> exhaustive kernels): all exact."""
+    rng = np.random.default_rng(81)
+    d = 1600
+    base = _unit(rng, 400, d)
+    c = np.ascontiguousarray(np.repeat(base, 25, axis=0)[rng.permutation(10000)])
+    q = _unit(rng, 20, d)
     idx = _index(c, cuda)
     D, I = idx.search(q, 100)
     Dr, Ir = sr.search_exact(q, c, 100)
+    assert idx.last_scan == "long" and np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    c2 = _unit(rng, 40000, d)
+    c2 = np.ascontiguousarray(c2[np.argsort(c2 @ q[0])])
+    idx = _index(c2, cuda)
+    D, I = idx.search(q, 10)
+    Dr, Ir = sr.search_exact(q, c2, 10)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    c3 = np.tile(_unit(rng, 1, d), (12000, 1))              # 12000 identical rows: more ties than the capacity
+    idx = _index(c3, cuda)
+    D, I = idx.search(q[:3], 10)
+    assert idx.last_fallback_queries == 3 and np.array_equal(I, np.tile(np.arange(10), (3, 1)))
+
+
+def test_long_rows_bf16_index_and_id_offset(cuda):
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(82)
+    n, nq, d, k = 30000, 70, 1024, 100
+    q, c = _bf16_round(_unit(rng, nq, d)), _bf16_round(_unit(rng, n, d))
+    idx = FlatIndex(d, "ip", cuda, dtype="bf16")
+    idx.add(c)
+    idx.id_offset = 5_000_000
+    D, I = idx.search(q, k)
+    assert idx.last_scan == "long"
+    Dr, Ir = sr.search_exact(q, c, k, id_offset=5_000_000)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
