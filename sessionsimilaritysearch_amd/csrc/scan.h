@@ -113,5 +113,6 @@ struct ThrArgs {
 };
 int launch_thr_prepare(const ThrArgs& a, hipStream_t st);
 int launch_select_all(const ThrArgs& a, hipStream_t st);
+int launch_bound_from_scan(const ThrArgs& a, hipStream_t st);   // intermediate levels of sss_ip_topk_long: bound only, no row read
 
 }  // namespace sss

@@ -11,15 +11,16 @@
 // The top-k rides on the THRESHOLD machinery of the rung (select.hip: THRESHOLD RUNG) instead of running lists:
 // the epilogue of a tile only compares its 128 scores per lane with the lane's fixed threshold and appends what
 // passes.  The threshold comes from LEVELS of evenly spread row samples:
-//   level 1   a few tiles (<= 4096 rows), threshold -inf: every sampled row is kept, k_select_all re-scores them
-//             canonically (float64) -> the exact top-k of the sample, whose k-th score is a valid LOWER BOUND of the
-//             true k-th score;
-//   level i   a sample `factor` times larger scanned with threshold = (bound - scan error bound - one ulp):
-//             about k * factor rows pass per query, all re-scored -> the exact top-k of that sample, a tighter bound;
+//   level 1   a sample of >= 2k rows, threshold -inf: every sampled row is kept; at least k of them have a scan
+//             score >= the k-th largest kept scan score s_k, hence an exact score >= s_k - (scan error bound): a
+//             valid LOWER BOUND of the true k-th score (k_bound_from_scan: a sort of scan scores, no row is read);
+//   level i   a sample `fmax` times larger scanned with threshold = (bound - error bound - one ulp): about
+//             k * fmax rows pass per query -> a tighter bound the same way;
 //   last      every row.  What passes is everything that can still reach the k-th score already known -- near ties
-//             and duplicate rows included -- so the canonical re-score of all of it IS the exact answer
-//             (status 0); a query with more than 8192 such rows keeps status 1 and goes to the exhaustive kernels.
-// Two to three passes, the last one dominant; no per-lane list, no shared threshold slots, no bootstrap.
+//             and duplicate rows included -- so the canonical float64 re-score of all of it (k_select_all) IS the
+//             exact answer (status 0); a query with more than 8192 such rows keeps status 1 and goes to the
+//             exhaustive kernels.  The last sample is 1/8 of the corpus: ~8 k rows per query reach the re-score.
+// Three to four passes, the last one dominant; no per-lane list, no shared threshold slots, no bootstrap.
 #include "scan.h"
 #include "scan_dev.h"
 
@@ -190,8 +191,6 @@ size_t ip_topk_long_workspace_bytes(long nq, long n, int d, int dtype) {
     return al256((size_t)nq * d * 2) + al256((size_t)nq * 4) * 3 + (size_t)nq * LONG_CAP * 8;
 }
 
-int launch_thr_prepare(const ThrArgs& a, hipStream_t st);
-int launch_select_all(const ThrArgs& a, hipStream_t st);
 
 __global__ void k_iota(int* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -229,15 +228,21 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     int rc = check_launch("k_query_f16 / k_iota");
     if (rc) return rc;
 
-    // ---- levels: 16 tiles, then `factor` times more per level until every tile is scanned; about k * factor rows pass
-    // a level's threshold, so factor <= cap / (4 k) keeps a 2x margin below the capacity
+    // ---- levels.  Tile counts grow geometrically: first a sample of >= 2k rows, kept whole (threshold -inf); then
+    // `fmax` times more rows per level -- about k * fmax rows pass a level's threshold, fmax = cap / (4 k) keeps a
+    // 2x margin below the capacity; the last sample is 1/8 of the corpus, so that only ~8 k rows per query pass
+    // the final threshold and have to be read back for the canonical re-score.  Intermediate levels read no row at
+    // all (k_bound_from_scan); the samples add 1/8 + 1/(8 fmax) + ... ~ 15 % to the matrix work.
     const int total_tiles = (int)((n + LT_ROWS - 1) / LT_ROWS);
     int fmax = LONG_CAP / (4 * k);
     if (fmax < 2) fmax = 2;
-    int levels = 1;
-    for (double t = 16; t < total_tiles; t *= fmax) ++levels;
-    const double factor = levels > 1 ? pow((double)total_tiles / 16.0, 1.0 / (levels - 1)) : 1.0;
-
+    int first = (2 * k + LT_ROWS - 1) / LT_ROWS;
+    if (first < 1) first = 1;
+    int level_tiles[40];
+    int levels = 0;
+    level_tiles[levels++] = total_tiles;
+    for (int t = total_tiles / 8; t > first && levels < 38; t /= fmax) level_tiles[levels++] = t;
+    if (level_tiles[levels - 1] > first) level_tiles[levels++] = first;          // (descending; run in reverse)
     ThrArgs t;
     t.Q = q; t.C = c_exact; t.qsel = qsel; t.nsel = (int)nq; t.d = d; t.dtype = exact_dtype; t.k = k; t.cap = LONG_CAP;
     t.scan_dtype = scan_dtype; t.corpus_shift = corpus_shift; t.corpus_resid = corpus_resid; t.corpus_max_norm = corpus_max_norm;
@@ -247,17 +252,17 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     a.total_tiles = total_tiles; a.cap = LONG_CAP; a.thr = thr; a.cnt = cnt; a.cand = cand;
     static bool attr_done[MAX_DEVICES][2] = {};
     const int dev = current_device();
-    for (int lv = 0; lv < levels; ++lv) {
-        int tiles = lv == levels - 1 ? total_tiles : (int)(16.0 * pow(factor, lv) + 0.5);
-        if (tiles > total_tiles) tiles = total_tiles;
+    for (int lv = levels - 1; lv >= 0; --lv) {
+        const int tiles = level_tiles[lv];
+        const bool last = lv == 0;
         a.tile_count = tiles;
         int S = (256 / a.G) & ~7;
         if (S < 8) S = 8;
         while (S > 8 && S > tiles) S -= 8;
         a.S = S;
         a.tiles_per_split = (tiles + S - 1) / S;
-        t.n = (long)tiles * LT_ROWS < n ? (long)tiles * LT_ROWS : n;       // rows this level can see (k_select_all: "at least min(k, n) kept")
-        if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(status), 1, (size_t)nq, st) != hipSuccess) { set_error("ip_topk_long: memset failed"); return SSS_EHIP; }
+        t.n = n;
+        if (last && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(status), 1, (size_t)nq, st) != hipSuccess) { set_error("ip_topk_long: memset failed"); return SSS_EHIP; }
         rc = launch_thr_prepare(t, st);                                     // thresholds from column k-1 of D_out; counters zeroed
         if (rc) return rc;
         const size_t lds = 2 * (size_t)LT_STAGE;
@@ -271,7 +276,7 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
         else hipLaunchKernelGGL(k_scan_long<DT_BF16>, dim3(a.S * a.G), dim3(512), lds, st, a);
         rc = check_launch("k_scan_long");
         if (rc) return rc;
-        rc = launch_select_all(t, st);
+        rc = last ? launch_select_all(t, st) : launch_bound_from_scan(t, st);
         if (rc) return rc;
     }
     return SSS_OK;

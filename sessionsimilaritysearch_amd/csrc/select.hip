@@ -474,11 +474,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
 // fit the candidate capacity; otherwise the query stays unproven and goes to the exhaustive kernels.
 //
 // k_thr_prepare: one wave per selected query: its threshold in the scan's domain, counter zeroed.
-__global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= A.nsel) return;
-    const int q = A.qsel[i];
+// B (scan error bound) and unscale (scan score -> score factor) of query row q, computed by ONE wave (all 64 lanes
+// call it; every lane returns the same values).
+__device__ __forceinline__ void query_bound(const ThrArgs& A, int q, int lane, double& B, double& unscale) {
     const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
     const char* qrow = reinterpret_cast<const char*>(A.Q) + (size_t)q * rb;
     double qn2 = 0.0;
@@ -497,9 +495,18 @@ __global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) rq2 += __shfl_xor(rq2, o);
     }
+    B = err_bound(A.d, A.scan_dtype, sqrt(qn2), (double)A.corpus_max_norm, (double)A.corpus_resid, sqrt(rq2));
+    unscale = A.scan_dtype == DT_F16 ? ldexp(1.0, -(A.corpus_shift + f16_shift(q_amax))) : 1.0;
+}
+
+__global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= A.nsel) return;
+    const int q = A.qsel[i];
+    double B, unscale;
+    query_bound(A, q, lane, B, unscale);
     if (lane != 0) return;
-    const double B = err_bound(A.d, A.scan_dtype, sqrt(qn2), (double)A.corpus_max_norm, (double)A.corpus_resid, sqrt(rq2));
-    const double unscale = A.scan_dtype == DT_F16 ? ldexp(1.0, -(A.corpus_shift + f16_shift(q_amax))) : 1.0;
     const double lb = (double)A.D_out[(size_t)q * A.k + A.k - 1];          // -FLT_MAX when no k-th score is known
     // rows the scan does NOT keep have scan score <= thr, hence exact score <= thr * unscale + B < lb - ulp32(lb)
     const double t = (lb - B - 2.4e-7 * fabs(lb) - 1e-44) / unscale;
@@ -510,39 +517,43 @@ __global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
     A.cnt[i] = 0u;
 }
 
+__device__ __forceinline__ void sort_desc(unsigned long long* keys, int M2, int tid);
+
+// k_bound_from_scan (sss_ip_topk_long, intermediate levels): no row is read.  At least k of the kept rows have a
+// scan score >= the k-th largest kept scan score s_k, so at least k rows have an exact score >= s_k * unscale - B:
+// a valid LOWER BOUND of the query's true k-th score, written to column k-1 of its row of D_out (where the next
+// level's k_thr_prepare reads it).  Left unchanged when the kept rows overflowed the capacity or are fewer than k.
+__global__ __launch_bounds__(SORT_THREADS) void k_bound_from_scan(const ThrArgs A, int cap_pow2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);             // [cap_pow2]
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int q = A.qsel[i];
+    const int k = A.k;
+    const unsigned M = A.cnt[i];
+    if (M > (unsigned)A.cap || (int)M < k) return;
+    int M2 = 64;
+    while (M2 < (int)M) M2 <<= 1;
+    const unsigned long long* ck = A.cand + (size_t)i * A.cap;
+    for (int c = tid; c < M2; c += SORT_THREADS) keys[c] = c < (int)M ? ck[c] : 0ull;
+    __syncthreads();
+    sort_desc(keys, M2, tid);
+    if (tid < 64) {
+        double B, unscale;
+        query_bound(A, q, tid, B, unscale);
+        if (tid == 0) {
+            const double lb = (double)key_score(keys[k - 1]) * unscale - B;
+            float f = (float)lb;
+            if ((double)f > lb) f = nextafterf(f, -INFINITY);              // round DOWN: stays a lower bound
+            if (f == f && f > A.D_out[(size_t)q * k + k - 1]) A.D_out[(size_t)q * k + k - 1] = f;
+        }
+    }
+}
+
 // k_select_all: one workgroup per selected query: canonical float64 re-score of EVERY kept row, bitonic sort
 // by (score desc, id asc), first k written.  status[q] = 0 when the kept rows fit the capacity (and there are
 // at least min(k, n) of them); untouched otherwise.
-__global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, int cap_pow2) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);             // [cap_pow2]
-    char* qrow = reinterpret_cast<char*>(keys + cap_pow2);
-    const int i = blockIdx.x, tid = threadIdx.x;
-    const int q = A.qsel[i];
-    const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
-    const int k = A.k;
-    const unsigned M = A.cnt[i];
-    const long need = (long)k < (long)A.n ? k : A.n;
-    if (M > (unsigned)A.cap || (long)M < need) return;                  // overflow (or NaNs): stays unproven
-    int M2 = 64;
-    while (M2 < (int)M) M2 <<= 1;
-    for (int v = tid; v < rb / 16; v += SORT_THREADS)
-        reinterpret_cast<f32x4*>(qrow)[v] = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.Q) + (size_t)q * rb)[v];
-    __syncthreads();
-    const unsigned long long* ck = A.cand + (size_t)i * A.cap;
-    for (int c = tid; c < M2; c += SORT_THREADS) {
-        unsigned long long key = 0ull;
-        if (c < (int)M) {
-            const int id = key_id(ck[c]);
-            const char* row = reinterpret_cast<const char*>(A.C) + (size_t)id * rb;
-            double acc = 0.0;
-            for (int v = 0; v < rb / 16; ++v)
-                acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
-            key = make_key((float)acc, id);
-        }
-        keys[c] = key;
-    }
-    __syncthreads();
+// descending bitonic sort of keys[0 .. M2) (M2 a power of two) by the whole workgroup
+__device__ __forceinline__ void sort_desc(unsigned long long* keys, int M2, int tid) {
     for (int kk = 2; kk <= M2; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
             for (int x = tid; x < M2; x += SORT_THREADS) {
@@ -556,10 +567,72 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
             __syncthreads();
         }
     }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, int cap_pow2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);             // [cap_pow2]
+    char* qrow = reinterpret_cast<char*>(keys + cap_pow2);
+    __shared__ float s_cut;
+    __shared__ int s_keep;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int q = A.qsel[i];
+    const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
+    const int k = A.k;
+    const unsigned M = A.cnt[i];
+    const long need = (long)k < (long)A.n ? k : A.n;
+    if (M > (unsigned)A.cap || (long)M < need) return;                  // overflow (or NaNs): stays unproven
+    int M2 = 64;
+    while (M2 < (int)M) M2 <<= 1;
+    for (int v = tid; v < rb / 16; v += SORT_THREADS)
+        reinterpret_cast<f32x4*>(qrow)[v] = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.Q) + (size_t)q * rb)[v];
+    const unsigned long long* ck = A.cand + (size_t)i * A.cap;
+    for (int c = tid; c < M2; c += SORT_THREADS) keys[c] = c < (int)M ? ck[c] : 0ull;
+    if (tid == 0) s_keep = (int)M;
+    __syncthreads();
+    // ---- prune by SCAN score before any row is read: with s_k the k-th largest kept scan score, at least k rows have
+    // an exact score >= s_k * unscale - B, and a row whose scan score lies more than 2 B below s_k cannot reach that.
+    // (Only worth a sort when there is much to prune; the kept set stays a superset of every possible result.)
+    if ((int)M > 2 * k + 64) {
+        sort_desc(keys, M2, tid);
+        if (tid < 64) {
+            double B, unscale;
+            query_bound(A, q, tid, B, unscale);
+            if (tid == 0) {
+                const double sk = (double)key_score(keys[k - 1]);
+                const double c = sk - (2.0 * B + 2.4e-7 * fabs(sk * unscale) + 1e-44) / unscale;
+                float f = (float)c;
+                if ((double)f > c) f = nextafterf(f, -INFINITY);
+                s_cut = f == f ? f : -INFINITY;                         // (NaN bound: keep everything)
+            }
+        }
+        __syncthreads();
+        const float cut = s_cut;
+        for (int c = tid; c < (int)M; c += SORT_THREADS)                // sorted descending: the kept prefix ends at one place
+            if (key_score(keys[c]) >= cut && (c + 1 == (int)M || !(key_score(keys[c + 1]) >= cut))) s_keep = c + 1;
+        __syncthreads();
+    }
+    const int keep = s_keep;
+    int K2 = 64;
+    while (K2 < keep) K2 <<= 1;
+    for (int c = tid; c < K2; c += SORT_THREADS) {
+        unsigned long long key = 0ull;
+        if (c < keep) {
+            const int id = key_id(keys[c]);
+            const char* row = reinterpret_cast<const char*>(A.C) + (size_t)id * rb;
+            double acc = 0.0;
+            for (int v = 0; v < rb / 16; ++v)
+                acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
+            key = make_key((float)acc, id);
+        }
+        keys[c] = key;
+    }
+    __syncthreads();
+    sort_desc(keys, K2, tid);
     float* Dq = A.D_out + (size_t)q * k;
     long* Iq = A.I_out + (size_t)q * k;
     for (int j = tid; j < k; j += SORT_THREADS) {
-        if (j < (int)M) { Dq[j] = key_score(keys[j]); Iq[j] = (long)key_id(keys[j]) + A.id_offset; }
+        if (j < keep) { Dq[j] = key_score(keys[j]); Iq[j] = (long)key_id(keys[j]) + A.id_offset; }
         else { Dq[j] = -3.4028234663852886e38f; Iq[j] = -1; }
     }
     if (tid == 0) A.status[q] = 0;
@@ -627,6 +700,20 @@ int launch_select(const SelectArgs& a, hipStream_t st) {
 int launch_thr_prepare(const ThrArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_thr_prepare, dim3((unsigned)((a.nsel + 3) / 4)), dim3(256), 0, st, a);
     return check_launch("k_thr_prepare");
+}
+
+int launch_bound_from_scan(const ThrArgs& a, hipStream_t st) {
+    int cap_pow2 = 64;
+    while (cap_pow2 < a.cap) cap_pow2 <<= 1;
+    const size_t lds = (size_t)cap_pow2 * 8;
+    static bool done[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!done[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bound_from_scan), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL(k_bound_from_scan, dim3((unsigned)a.nsel), dim3(SORT_THREADS), lds, st, a, cap_pow2);
+    return check_launch("k_bound_from_scan");
 }
 
 int launch_select_all(const ThrArgs& a, hipStream_t st) {
