@@ -1,61 +1,77 @@
 """Dev helper: copy the judged summaries of a scripts/collect_profiles.sh run from gpurun_out/prof_<tag>/ into
 profiles/ (kernel stats, bench lines, per-kernel PMC means) and write profiles/<tag>_traffic.json, which bench.py
-reads for `roofline.traffic`.      python scripts/summarize_profiles.py r02"""
-import csv, json, os, shutil, sys
+reads for `roofline.traffic` -- every entry stamped with the sha256 of the csrc/scan.hip it was measured on
+(bench.py prints null for a stale entry).      python scripts/summarize_profiles.py r03"""
+import csv, hashlib, json, os, re, shutil, sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", "prof_" + tag), os.path.join(root, "profiles")
-for name in ("bench_default", "bench_split", "bench_f32", "bench_c4_10m", "bench_c4_10m_f32", "bench_c5_bf16", "bench_c3",
-             "encoder", "search_shapes"):
-    shutil.copy(f"{src}/{name}_kernel_stats.csv", f"{dst}/{tag}_{name}_kernel_stats.csv")
+sha = hashlib.sha256(open(os.path.join(root, "sessionsimilaritysearch_amd", "csrc", "scan.hip"), "rb").read()).hexdigest()[:16]
+for name in ("bench_default", "bench_split", "bench_c4_10m", "bench_c5_bf16", "bench_c3", "encoder", "search_shapes"):
+    if os.path.exists(f"{src}/{name}_kernel_stats.csv"):
+        shutil.copy(f"{src}/{name}_kernel_stats.csv", f"{dst}/{tag}_{name}_kernel_stats.csv")
     lj = f"{src}/{name}_line.json"
     if os.path.exists(lj) and os.path.getsize(lj) > 0:
         shutil.copy(lj, f"{dst}/{tag}_{name}_line.json")
 if os.path.exists(f"{src}/components.txt"):
     shutil.copy(f"{src}/components.txt", f"{dst}/{tag}_components.txt")
 for name in ("search_shapes", "encoder"):
-    lines = [l for l in open(f"{src}/{name}.log") if l.startswith("{") or l.startswith("sessions=")]
-    open(f"{dst}/{tag}_{name}_lines.txt", "w").writelines(lines)
+    if os.path.exists(f"{src}/{name}.log"):
+        lines = [l for l in open(f"{src}/{name}.log") if l.startswith("{") or l.startswith("sessions=")]
+        open(f"{dst}/{tag}_{name}_lines.txt", "w").writelines(lines)
+
+DT = {"0": "f32", "1": "bf16", "2": "split", "3": "f16"}
+
+
+def scan_type(kernel):
+    """k_scan<row bytes, tile rows, element type, waves, threshold form> -> 'f32' | 'bf16' | 'split' | 'f16'"""
+    m = re.search(r"k_scan<\s*\d+,\s*\d+,\s*(\d)", kernel)
+    return DT.get(m.group(1)) if m else None
 
 
 def summarize(name):
-    rows = list(csv.DictReader(open(f"{src}/{name}_counters.csv")))
+    path = f"{src}/{name}_counters.csv"
+    if not os.path.exists(path):
+        return {}
     agg = defaultdict(list)
-    for r in rows:
+    for r in csv.DictReader(open(path)):
         kn = r["Kernel_Name"]
-        if "k_scan<" in kn or "k_select" in kn:
+        if "k_scan" in kn or "k_select" in kn:
             agg[(kn.split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     with open(f"{dst}/{tag}_{name}.csv", "w") as f:
         f.write("kernel,counter,launches,mean_per_launch\n")
         for (k, c), v in sorted(agg.items()):
             f.write(f'"{k}",{c},{len(v)},{sum(v) / len(v):.3f}\n')
-    return {(k, c): sum(v) / len(v) for (k, c), v in agg.items()}
+    return {(scan_type(k), c): sum(v) / len(v) for (k, c), v in agg.items() if scan_type(k)}
 
 
-scan = lambda d: [v for (k, c), v in d.items() if "k_scan<" in k][0]
-fetch, write = scan(summarize("pmc_fetch")), scan(summarize("pmc_write"))
-for name in ("pmc_mfma", "pmc_issue", "pmc_lds", "pmc_mfma_split", "pmc_mfma_f32", "pmc_mfma_c5"):
+fetch, write = summarize("pmc_fetch"), summarize("pmc_write")
+for name in ("pmc_mfma", "pmc_issue", "pmc_mfma_c5"):
     summarize(name)
-fetch_split, fetch_f32, fetch5 = scan(summarize("pmc_fetch_split")), scan(summarize("pmc_fetch_f32")), scan(summarize("pmc_fetch_c5"))
+fetch_split, fetch5 = summarize("pmc_fetch_split"), summarize("pmc_fetch_c5")
 n1, nq1, d1 = 1000000, 1024, 128
-traffic = {
-    "_doc": "HBM bytes per launch of the scan kernel from rocprofv3 --pmc passes (scripts/collect_profiles.sh). FETCH_SIZE / "
-            "WRITE_SIZE are reported in KB; FETCH_SIZE counts 16-B/lane streaming reads at half (MI355X_MICROARCH.md 'HBM'): "
-            "bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024.  Key = scan:d:nq:rows_per_gpu; algorithmic_bytes = the scanned corpus "
-            "image once + the query batch.",
-    f"f16:{d1}:{nq1}:{n1}": {"fetch_bytes": round(fetch * 2048), "write_bytes": round(write * 1024),
-                             "total_bytes": round(fetch * 2048 + write * 1024),
-                             "algorithmic_bytes": n1 * d1 * 2 + nq1 * d1 * 4,
-                             "source": f"profiles/{tag}_pmc_fetch.csv + {tag}_pmc_write.csv"},
-    f"split:{d1}:{nq1}:{n1}": {"fetch_bytes": round(fetch_split * 2048), "write_bytes": None, "total_bytes": round(fetch_split * 2048),
-                               "algorithmic_bytes": n1 * d1 * 4 + nq1 * d1 * 4, "source": f"profiles/{tag}_pmc_fetch_split.csv"},
-    f"f32:{d1}:{nq1}:{n1}": {"fetch_bytes": round(fetch_f32 * 2048), "write_bytes": None, "total_bytes": round(fetch_f32 * 2048),
-                             "algorithmic_bytes": n1 * d1 * 4 + nq1 * d1 * 4, "source": f"profiles/{tag}_pmc_fetch_f32.csv"},
-    "bf16:256:4096:10000000": {"fetch_bytes": round(fetch5 * 2048), "write_bytes": None, "total_bytes": round(fetch5 * 2048),
-                               "algorithmic_bytes": 10000000 * 256 * 2 + 4096 * 256 * 2,
-                               "source": f"profiles/{tag}_pmc_fetch_c5.csv"},
-}
+doc = ("HBM bytes per launch of the scan kernel from rocprofv3 --pmc passes (scripts/collect_profiles.sh). FETCH_SIZE / "
+       "WRITE_SIZE are reported in KB; FETCH_SIZE counts 16-B/lane streaming reads at half (MI355X_MICROARCH.md 'HBM'): "
+       "bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024.  Key = scan:d:nq:rows_per_gpu; algorithmic_bytes = the scanned corpus "
+       "image once + the query batch.  scan_hip_sha16 = sha256 of the csrc/scan.hip the counters were collected on.")
+traffic = {"_doc": doc}
+
+
+def entry(key, fetch_kb, write_kb, alg, source):
+    if fetch_kb is None:
+        return
+    traffic[key] = {"fetch_bytes": round(fetch_kb * 2048), "write_bytes": None if write_kb is None else round(write_kb * 1024),
+                    "total_bytes": round(fetch_kb * 2048 + (write_kb or 0) * 1024), "algorithmic_bytes": alg,
+                    "scan_hip_sha16": sha, "source": source}
+
+
+entry(f"f16:{d1}:{nq1}:{n1}", fetch.get(("f16", "FETCH_SIZE")), write.get(("f16", "WRITE_SIZE")), n1 * d1 * 2 + nq1 * d1 * 4,
+      f"profiles/{tag}_pmc_fetch.csv + {tag}_pmc_write.csv")
+entry(f"f32:{d1}:{nq1}:{n1}", fetch.get(("f32", "FETCH_SIZE")), write.get(("f32", "WRITE_SIZE")), n1 * d1 * 4 + nq1 * d1 * 4,
+      f"profiles/{tag}_pmc_fetch.csv + {tag}_pmc_write.csv")
+entry(f"split:{d1}:{nq1}:{n1}", fetch_split.get(("split", "FETCH_SIZE")), None, n1 * d1 * 4 + nq1 * d1 * 4, f"profiles/{tag}_pmc_fetch_split.csv")
+entry("bf16:256:4096:10000000", fetch5.get(("bf16", "FETCH_SIZE")), None, 10000000 * 256 * 2 + 4096 * 256 * 2, f"profiles/{tag}_pmc_fetch_c5.csv")
 json.dump(traffic, open(f"{dst}/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))

@@ -136,10 +136,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             if (qi > nq - 1) qi = nq - 1;
             const unsigned off = (unsigned)qi * 64u + (unsigned)(lane & 3) * 16u;
             const unsigned dst = __builtin_amdgcn_readfirstlane(tau_lds + j * 1024);
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, %3 sc1\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(off), "s"(dst), "s"(A.slots) : "memory");
+            // (M0 is written without a save / restore: hipcc has no use of its own for M0 in this kernel -- no dynamic
+            //  register indexing, no LDS-direct / GWS / sendmsg; every M0 reference in the ISA comes from these statements)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 sc1"
+                         : : "v"(off), "s"(dst), "s"(A.slots) : "memory");
         }
     };
     auto tau_read = [&]() -> unsigned {
@@ -203,10 +203,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             if (grow > (long)n - 1) grow = (long)n - 1;
             off = (unsigned)((grow - row0) * RB) + (off - (unsigned)(lr * RB));
         }
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(off), "s"(dst), "s"(tile_src) : "memory");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                     : : "v"(off), "s"(dst), "s"(tile_src) : "memory");
     };
     auto stage = [&](int buf, int tile_idx) {
 #pragma unroll
@@ -382,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     // MFMAs of step t into acc0 / acc1 (acc[j] is (corpus row row0 + (j&3) + 8*(j>>2) + 4h, query r),
     // acc1 32 rows further); returns the lane's maximum over both.
     auto score_step = [&](int t) -> float {
-        const int i = t / H, sub = t % H;
+        const int i = (int)((unsigned)t / (unsigned)H), sub = (int)((unsigned)t % (unsigned)H);   // (unsigned: shifts, not the signed-division sequence)
         if (sub == 0) tile_top(i);
         const int next_tile = (i + 1 < niter) ? tile_of(i + 1) : -1;
         mfma_sub(i & 1, sub, next_tile);
@@ -411,7 +409,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         for (; t < T; ++t) {                    // ---- hot loop
             const float m = score_step(t);
             if (t >= t_live && __builtin_amdgcn_ballot_w64(m > thr) != 0) { rare = true; break; }
-            if (t % H == H - 1) tile_end(t / H);
+            if ((unsigned)t % (unsigned)H == H - 1) tile_end((int)((unsigned)t / (unsigned)H));
         }
         if (!rare) break;
         if constexpr (THR) {
@@ -421,7 +419,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             insert_block(acc0, (int)row0_of_step + 4 * h);
             insert_block(acc1, (int)row0_of_step + 32 + 4 * h);
         }
-        if (t % H == H - 1) tile_end(t / H);
+        if ((unsigned)t % (unsigned)H == H - 1) tile_end((int)((unsigned)t / (unsigned)H));
         ++t;
     }
     if constexpr (THR) return;
