@@ -149,6 +149,41 @@ def test_encoder_matches_oracle(cuda, d, layers, n, loops, fused):
     assert np.abs(gn - rn_).max() < TOL
 
 
+def test_grouped_linear_large_batch_variant_is_bit_identical(cuda):
+    """Corpus-build batches take the 128 x 128-tile variant of sss_linear_grouped; query batches the 64 x 64 one.  Every
+    output element is the same k-ordered f32 fma chain either way, so the two must agree BIT FOR BIT -- also in gather
+    mode (rows = table[ids], copied to slice 0 of the node buffer) and through the activation epilogues."""
+    from sessionsimilaritysearch_amd.variants import _prob
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    n_p, n_q, K = 150_001, 90_000, 128
+    table = torch.randn((5000, K), generator=g).to(cuda)
+    ids = torch.randint(0, 5000, (n_p,), generator=g).to(cuda)
+    xq = torch.randn((n_q, K), generator=g).to(cuda)
+    wp, bp = torch.randn((898, K), generator=g).to(cuda), torch.randn(898, generator=g).to(cuda)
+    wq = torch.randn((130, K), generator=g).to(cuda)
+
+    def run(lo_p, hi_p, lo_q, hi_q, act):
+        yp = torch.empty((hi_p - lo_p, 898 + 2), device=cuda)
+        yq = torch.empty((hi_q - lo_q, 130), device=cuda)
+        xc = torch.zeros((hi_p - lo_p, K + 4), device=cuda)
+        pp = _lib.LinearProblem(x=0, ldx=0, ids=ids[lo_p:hi_p].data_ptr(), table=table.data_ptr(), xcopy=xc.data_ptr(), ld_xcopy=K + 4,
+                                w=wp.data_ptr(), ldw=K, bias=bp.data_ptr(), y=yp.data_ptr(), ldy=900, n=hi_p - lo_p, m=898, act=act)
+        pq = _prob(xq[lo_q:hi_q], wq, None, yq, hi_q - lo_q, 130, act)
+        _lib.check(L.sss_linear_grouped((_lib.LinearProblem * 2)(pp, pq), 2, K, _st(cuda)), "grouped")
+        return yp[:, :898], yq, xc[:, :K]
+    for act in (0, 2):
+        big_p, big_q, big_x = run(0, n_p, 0, n_q, act)                   # 1176 + ... big tiles: the 128 x 128 variant
+        for lo in (0, 70_000, n_p - 3000):
+            sp, sq, sx = run(lo, lo + 3000, min(lo, n_q - 3000), min(lo, n_q - 3000) + 3000, act)   # small: the 64 x 64 variant
+            assert torch.equal(sp, big_p[lo:lo + 3000]) and torch.equal(sx, big_x[lo:lo + 3000])
+            qlo = min(lo, n_q - 3000)
+            assert torch.equal(sq, big_q[qlo:qlo + 3000])
+    ref = table[ids[:2000]].double() @ wp.double().T + bp.double()
+    got, _, _ = run(0, n_p, 0, n_q, 0)
+    assert (got[:2000].double() - ref).abs().max() <= 2e-6 * float(ref.abs().max()) * np.sqrt(K / 32)
+
+
 def test_encoder_at_the_reference_model_shapes(cuda):
     """The deployed model's shapes: 768-wide node features (rows of random feature tables here -- the text encoder
     that produces them upstream is out of scope), h = 800, 3 layers, node width 3168, session vector D = 1600,
