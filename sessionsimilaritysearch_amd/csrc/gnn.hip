@@ -555,120 +555,6 @@ __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
 }
 
 // ------------------------------------------------------------------------------------------
-// The same grouped node-linear for LARGE batches (corpus build: tens of thousands of sessions per launch): 128 x 128
-// output tiles, four waves as 2 x 2, each wave four 32 x 32 accumulators -- every A / B fragment read from LDS feeds
-// two MFMAs and a K chunk of 32 carries 64 MFMAs per wave instead of 16, so the per-chunk barriers, staging and
-// address arithmetic that pace the 64 x 64 latency variant (query batches: many small workgroups resident at once)
-// are spread over four times the matrix work.  Same fetch -> LDS -> MFMA pipeline, same bit-exact k-ordered f32
-// fma chains per output element (the k order of a chain does not depend on the tile shape), same epilogue.
-constexpr int LTB = 128;
-__global__ __launch_bounds__(256, 2) void k_linear_grouped_big(const LinBatch B) {
-    constexpr int KC = 32;
-    constexpr int CPR = KC / 4;                 // 16-byte chunks per staged row
-    constexpr int NLD = LTB * CPR / 256;        // float4 loads per thread per operand per chunk (4)
-    constexpr int RS = CPR;
-    constexpr int SW = RS - 1;
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    float* lx = lds_raw;
-    float* lw = lds_raw + LTB * RS * 4;
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < 4; ++i)
-        if (i < B.nprob && (int)blockIdx.x >= B.p[i].tile_begin) pi = i;
-    const float* X = B.p[0].x; long ldx = B.p[0].ldx; const long* ids = B.p[0].ids; const float* table = B.p[0].table;
-    float* xcopy = B.p[0].xcopy; long ldc = B.p[0].ld_xcopy; const float* W = B.p[0].w; long ldw = B.p[0].ldw;
-    const float* bias = B.p[0].bias; float* Y = B.p[0].y; long ldy = B.p[0].ldy; long N = B.p[0].n; int M = B.p[0].m;
-    int tiles_m = B.p[0].tiles_m, tile_begin = B.p[0].tile_begin, act = B.p[0].act;
-    const float* post_s = B.p[0].post_scale; const float* post_t = B.p[0].post_shift;
-#pragma unroll
-    for (int i = 1; i < 4; ++i)
-        if (pi == i) {
-            act = B.p[i].act; post_s = B.p[i].post_scale; post_t = B.p[i].post_shift;
-            X = B.p[i].x; ldx = B.p[i].ldx; ids = B.p[i].ids; table = B.p[i].table; xcopy = B.p[i].xcopy; ldc = B.p[i].ld_xcopy;
-            W = B.p[i].w; ldw = B.p[i].ldw; bias = B.p[i].bias; Y = B.p[i].y; ldy = B.p[i].ldy; N = B.p[i].n; M = B.p[i].m;
-            tiles_m = B.p[i].tiles_m; tile_begin = B.p[i].tile_begin;
-        }
-    const int K = B.K;
-    const int t = (int)blockIdx.x - tile_begin;
-    const long row0 = (long)(t / tiles_m) * LTB;
-    const int col0 = (t % tiles_m) * LTB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
-
-    f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
-    f32x4 sx[NLD], sw[NLD];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int p = tid + 256 * i;
-            const int tr = p / CPR, c = p % CPR;
-            long gr = row0 + tr; if (gr > N - 1) gr = N - 1;
-            int gw = col0 + tr; if (gw > M - 1) gw = M - 1;
-            const float* xrow = ids ? table + ids[gr] * (long)K : X + gr * ldx;
-            sx[i] = *reinterpret_cast<const f32x4*>(xrow + k0 + c * 4);
-            sw[i] = *reinterpret_cast<const f32x4*>(W + (long)gw * ldw + k0 + c * 4);
-            if (ids && xcopy && col0 == 0 && row0 + tr < N)          // the gathered rows = slice 0 of the node buffer
-                *reinterpret_cast<f32x4*>(xcopy + gr * ldc + k0 + c * 4) = sx[i];
-        }
-    };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        if (k0 > 0) __syncthreads();                         // previous chunk fully consumed
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int p = tid + 256 * i;
-            const int tr = p / CPR, c = p % CPR;
-            const int cs = c ^ (tr & SW);
-            *reinterpret_cast<f32x4*>(lx + (tr * RS + cs) * 4) = sx[i];
-            *reinterpret_cast<f32x4*>(lw + (tr * RS + cs) * 4) = sw[i];
-        }
-        __syncthreads();
-        if (k0 + KC < K) fetch(k0 + KC);                     // next chunk's loads fly under this chunk's MFMAs
-#pragma unroll
-        for (int u = 0; u < KC / 8; ++u) {
-            float4 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int xr = wr * 64 + i * 32 + r, wrow = wc * 64 + i * 32 + r;
-                a[i] = *reinterpret_cast<const float4*>(lx + (xr * RS + ((2 * u + h) ^ (xr & SW))) * 4);
-                b[i] = *reinterpret_cast<const float4*>(lw + (wrow * RS + ((2 * u + h) ^ (wrow & SW))) * 4);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-    }
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
-        const int col = col0 + wc * 64 + jb * 32 + r;
-        if (col >= M) continue;
-        const float bv = bias ? bias[col] : 0.f;
-        const float ps = post_s ? post_s[col] : 1.f, pt = post_s ? post_t[col] : 0.f;
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const long row = row0 + wr * 64 + ib * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-                float v = acc[ib][jb][j] + bv;
-                if (act == 1) v = fmaxf(v, 0.f);
-                else if (act == 2) v = tanhf(v);
-                else if (act == 3) v = v > 0.f ? 1.f : v < 0.f ? -1.f : v;
-                else if (act == 4) v = tanhf(tanhf(v));
-                if (post_s) v = fmaxf(v * ps + pt, 0.f);
-                if (row < N) Y[row * ldy + col] = v;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // One LPR-lane group per TARGET node (LPR = h / 4: a lane owns one float4 column of the h-wide
 // row).  Targets [0, Np) are products, [Np, Np + Nq) queries.
 //   product i:  t1 = GAT(query -> product)  (Appendix A.2: leaky_relu(0.2), per-target softmax,
@@ -1019,7 +905,6 @@ __global__ __launch_bounds__(256) void k_pool_attention_tab(const float* __restr
 int linear_grouped(LinBatch& b, hipStream_t st) {
     if (b.nprob < 1 || b.nprob > 4 || b.K <= 0 || b.K % 32) { set_error("linear_grouped: 1..4 problems, K %% 32 == 0"); return SSS_EINVAL; }
     int total = 0;
-    double work = 0.0;
     for (int i = 0; i < b.nprob; ++i) {
         LinProb& p = b.p[i];
         if (p.n < 0 || p.m <= 0 || p.ldw % 4 || p.ldw < b.K || p.ldy < p.m || (!p.ids && (p.ldx % 4 || p.ldx < b.K)) ||
@@ -1030,22 +915,6 @@ int linear_grouped(LinBatch& b, hipStream_t st) {
         p.tiles_m = (p.m + LT - 1) / LT;
         p.tile_begin = total;
         total += (int)((p.n + LT - 1) / LT) * p.tiles_m;
-        work += (double)p.n * p.m;
-    }
-    // corpus-build batches: the 128 x 128 variant once there are enough big tiles to fill the chip twice over
-    long big_tiles = 0;
-    for (int i = 0; i < b.nprob; ++i) big_tiles += ((b.p[i].n + LTB - 1) / LTB) * ((b.p[i].m + LTB - 1) / LTB);
-    if (big_tiles >= 1024 && work >= 64.0 * 1024 * 1024) {
-        total = 0;
-        for (int i = 0; i < b.nprob; ++i) {
-            LinProb& p = b.p[i];
-            p.tiles_m = (p.m + LTB - 1) / LTB;
-            p.tile_begin = total;
-            total += (int)((p.n + LTB - 1) / LTB) * p.tiles_m;
-        }
-        for (int i = b.nprob; i < 4; ++i) { b.p[i] = b.p[0]; b.p[i].tile_begin = 0x7fffffff; }
-        hipLaunchKernelGGL(k_linear_grouped_big, dim3((unsigned)total), dim3(256), 2 * LTB * 8 * 16, st, b);
-        return check_launch("k_linear_grouped_big");
     }
     for (int i = b.nprob; i < 4; ++i) { b.p[i] = b.p[0]; b.p[i].tile_begin = 0x7fffffff; }
     if (total == 0) return SSS_OK;
