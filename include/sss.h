@@ -130,7 +130,8 @@ int sss_ip_topk_threshold(const void* q, const int32_t* qsel, int64_t nsel, cons
                           int32_t* status, void* workspace, size_t workspace_bytes, void* stream);
 
 /* LONG rows (the reference's own D = 1600 session vectors, K = 100: pretrain_filtered_amazon.py:281,
- * test_amazon_filterd.py:459,578 -- `index.search(normalize(emb), K)`): any d % 64 == 0 up to 8192, k <= 4096.
+ * test_amazon_filterd.py:459,578 -- `index.search(normalize(emb), K)`): any d % 64 == 0 with rows of at most
+ * 16384 bytes (d <= 4096 float32, <= 8192 bfloat16), k <= 4096.
  * A K-tiled MFMA contraction (256 queries x 256 rows per workgroup tile, both operands streamed through LDS in
  * 128-byte slabs) whose top-k rides on thresholds instead of running lists: a few evenly spread row samples of
  * growing size give, level by level, a tighter lower bound of each query's k-th score; the last pass over every

@@ -181,7 +181,7 @@ constexpr int LONG_CAP = 8192;      // rows kept per query (k_select_all sorts t
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static bool long_shape_ok(int d, int exact_dtype, int scan_dtype) {
-    if (d <= 0 || d % 64 || d > 8192) return false;
+    if (d <= 0 || d % 64 || d * elem_bytes(exact_dtype) > 16384) return false;     // (k_select_all keeps the query row in LDS)
     return (exact_dtype == DT_F32 && scan_dtype == DT_F16) || (exact_dtype == DT_BF16 && scan_dtype == DT_BF16);
 }
 
@@ -202,7 +202,7 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
                  int* status, void* ws, size_t ws_bytes, hipStream_t st) {
     const int scan_dtype = exact_dtype == DT_F32 ? DT_F16 : DT_BF16;
     if (nq <= 0 || n <= 0 || k <= 0) { set_error("ip_topk_long: nq, n, k must be positive"); return SSS_EINVAL; }
-    if (!long_shape_ok(d, exact_dtype, scan_dtype)) { set_error("ip_topk_long: need dtype 0 / 1 and d %% 64 == 0, d <= 8192 (got dtype %d d %d)", exact_dtype, d); return SSS_EINVAL; }
+    if (!long_shape_ok(d, exact_dtype, scan_dtype)) { set_error("ip_topk_long: need dtype 0 / 1, d %% 64 == 0 and rows of at most 16384 bytes (got dtype %d d %d)", exact_dtype, d); return SSS_EINVAL; }
     if (!c_scan || (reinterpret_cast<uintptr_t>(c_scan) & 15)) { set_error("ip_topk_long: scan image missing or not 16-byte aligned"); return SSS_EINVAL; }
     if (n >= (1L << 31) - 1024 || nq >= (1L << 31)) { set_error("ip_topk_long: n and nq must be < 2^31"); return SSS_EINVAL; }
     if (2 * k > LONG_CAP) { set_error("ip_topk_long: k too large (max %d)", LONG_CAP / 2); return SSS_EINVAL; }

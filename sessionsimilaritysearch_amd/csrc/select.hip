@@ -517,41 +517,6 @@ __global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
     A.cnt[i] = 0u;
 }
 
-__device__ __forceinline__ void sort_desc(unsigned long long* keys, int M2, int tid);
-
-// k_bound_from_scan (sss_ip_topk_long, intermediate levels): no row is read.  At least k of the kept rows have a
-// scan score >= the k-th largest kept scan score s_k, so at least k rows have an exact score >= s_k * unscale - B:
-// a valid LOWER BOUND of the query's true k-th score, written to column k-1 of its row of D_out (where the next
-// level's k_thr_prepare reads it).  Left unchanged when the kept rows overflowed the capacity or are fewer than k.
-__global__ __launch_bounds__(SORT_THREADS) void k_bound_from_scan(const ThrArgs A, int cap_pow2) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);             // [cap_pow2]
-    const int i = blockIdx.x, tid = threadIdx.x;
-    const int q = A.qsel[i];
-    const int k = A.k;
-    const unsigned M = A.cnt[i];
-    if (M > (unsigned)A.cap || (int)M < k) return;
-    int M2 = 64;
-    while (M2 < (int)M) M2 <<= 1;
-    const unsigned long long* ck = A.cand + (size_t)i * A.cap;
-    for (int c = tid; c < M2; c += SORT_THREADS) keys[c] = c < (int)M ? ck[c] : 0ull;
-    __syncthreads();
-    sort_desc(keys, M2, tid);
-    if (tid < 64) {
-        double B, unscale;
-        query_bound(A, q, tid, B, unscale);
-        if (tid == 0) {
-            const double lb = (double)key_score(keys[k - 1]) * unscale - B;
-            float f = (float)lb;
-            if ((double)f > lb) f = nextafterf(f, -INFINITY);              // round DOWN: stays a lower bound
-            if (f == f && f > A.D_out[(size_t)q * k + k - 1]) A.D_out[(size_t)q * k + k - 1] = f;
-        }
-    }
-}
-
-// k_select_all: one workgroup per selected query: canonical float64 re-score of EVERY kept row, bitonic sort
-// by (score desc, id asc), first k written.  status[q] = 0 when the kept rows fit the capacity (and there are
-// at least min(k, n) of them); untouched otherwise.
 // descending bitonic sort of keys[0 .. M2) (M2 a power of two) by the whole workgroup
 __device__ __forceinline__ void sort_desc(unsigned long long* keys, int M2, int tid) {
     for (int kk = 2; kk <= M2; kk <<= 1) {
@@ -569,12 +534,65 @@ __device__ __forceinline__ void sort_desc(unsigned long long* keys, int M2, int 
     }
 }
 
+// The k-th largest score ordinal (high word of the keys) among keys[0 .. M), k <= M, by the whole workgroup: a
+// bit-by-bit descent -- "do at least k keys have an ordinal >= prefix | bit?" -- 32 counting rounds instead of a
+// sort of up to 8192 keys.  s_cnt: one shared word; every thread returns the same value.
+__device__ __forceinline__ unsigned kth_largest_ord(const unsigned long long* keys, int M, int k, int tid, unsigned* s_cnt) {
+    unsigned prefix = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        if (tid == 0) *s_cnt = 0u;
+        __syncthreads();
+        unsigned c = 0;
+        for (int x = tid; x < M; x += SORT_THREADS) c += (unsigned)(keys[x] >> 32) >= cand ? 1u : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += (unsigned)__shfl_xor((int)c, o);
+        if ((tid & 63) == 0 && c) atomicAdd(s_cnt, c);
+        __syncthreads();
+        if (*s_cnt >= (unsigned)k) prefix = cand;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// k_bound_from_scan (sss_ip_topk_long, intermediate levels): no row is read.  At least k of the kept rows have a
+// scan score >= the k-th largest kept scan score s_k, so at least k rows have an exact score >= s_k * unscale - B:
+// a valid LOWER BOUND of the query's true k-th score, written to column k-1 of its row of D_out (where the next
+// level's k_thr_prepare reads it).  Left unchanged when the kept rows overflowed the capacity or are fewer than k.
+__global__ __launch_bounds__(SORT_THREADS) void k_bound_from_scan(const ThrArgs A) {
+    __shared__ unsigned s_cnt;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int q = A.qsel[i];
+    const int k = A.k;
+    const unsigned M = A.cnt[i];
+    if (M > (unsigned)A.cap || (int)M < k) return;
+    const unsigned sk = kth_largest_ord(A.cand + (size_t)i * A.cap, (int)M, k, tid, &s_cnt);
+    if (tid < 64) {
+        double B, unscale;
+        query_bound(A, q, tid, B, unscale);
+        if (tid == 0) {
+            const double lb = (double)ord2f(sk) * unscale - B;
+            float f = (float)lb;
+            if ((double)f > lb) f = nextafterf(f, -INFINITY);              // round DOWN: stays a lower bound
+            if (f == f && f > A.D_out[(size_t)q * k + k - 1]) A.D_out[(size_t)q * k + k - 1] = f;
+        }
+    }
+}
+
+// k_select_all: one workgroup per selected query.  The kept rows are first pruned by SCAN score, before any row is
+// read: with s_k the k-th largest kept scan score, at least k rows have an exact score >= s_k * unscale - B, and a
+// row whose scan score lies more than 2 B (+ one float32 ulp) below s_k cannot reach that -- the survivors are a
+// superset of every possible result, typically k + a few.  They are re-scored canonically (float64, sequential in
+// k, from the stored rows), bitonic-sorted by (score desc, id asc), the first k written.  status[q] = 0 when the
+// kept rows fit the capacity (and there are at least min(k, n) of them); untouched otherwise.
 __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, int cap_pow2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);             // [cap_pow2]
-    char* qrow = reinterpret_cast<char*>(keys + cap_pow2);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);             // [cap_pow2] kept rows (scan keys)
+    unsigned long long* surv = keys + cap_pow2;                                          // [cap_pow2] survivors, then exact keys
+    char* qrow = reinterpret_cast<char*>(surv + cap_pow2);
+    __shared__ unsigned s_cnt;
     __shared__ float s_cut;
-    __shared__ int s_keep;
+    __shared__ unsigned s_keep;
     const int i = blockIdx.x, tid = threadIdx.x;
     const int q = A.qsel[i];
     const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
@@ -582,24 +600,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
     const unsigned M = A.cnt[i];
     const long need = (long)k < (long)A.n ? k : A.n;
     if (M > (unsigned)A.cap || (long)M < need) return;                  // overflow (or NaNs): stays unproven
-    int M2 = 64;
-    while (M2 < (int)M) M2 <<= 1;
     for (int v = tid; v < rb / 16; v += SORT_THREADS)
         reinterpret_cast<f32x4*>(qrow)[v] = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.Q) + (size_t)q * rb)[v];
     const unsigned long long* ck = A.cand + (size_t)i * A.cap;
-    for (int c = tid; c < M2; c += SORT_THREADS) keys[c] = c < (int)M ? ck[c] : 0ull;
-    if (tid == 0) s_keep = (int)M;
+    for (int c = tid; c < (int)M; c += SORT_THREADS) keys[c] = ck[c];
+    if (tid == 0) { s_cut = -INFINITY; s_keep = 0u; }
     __syncthreads();
-    // ---- prune by SCAN score before any row is read: with s_k the k-th largest kept scan score, at least k rows have
-    // an exact score >= s_k * unscale - B, and a row whose scan score lies more than 2 B below s_k cannot reach that.
-    // (Only worth a sort when there is much to prune; the kept set stays a superset of every possible result.)
-    if ((int)M > 2 * k + 64) {
-        sort_desc(keys, M2, tid);
+    if ((int)M > 2 * k + 64) {                                          // (worth a selection only when there is much to prune)
+        const unsigned sk_o = kth_largest_ord(keys, (int)M, k, tid, &s_cnt);
         if (tid < 64) {
             double B, unscale;
             query_bound(A, q, tid, B, unscale);
             if (tid == 0) {
-                const double sk = (double)key_score(keys[k - 1]);
+                const double sk = (double)ord2f(sk_o);
                 const double c = sk - (2.0 * B + 2.4e-7 * fabs(sk * unscale) + 1e-44) / unscale;
                 float f = (float)c;
                 if ((double)f > c) f = nextafterf(f, -INFINITY);
@@ -607,25 +620,27 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
             }
         }
         __syncthreads();
-        const float cut = s_cut;
-        for (int c = tid; c < (int)M; c += SORT_THREADS)                // sorted descending: the kept prefix ends at one place
-            if (key_score(keys[c]) >= cut && (c + 1 == (int)M || !(key_score(keys[c + 1]) >= cut))) s_keep = c + 1;
-        __syncthreads();
     }
-    const int keep = s_keep;
+    const float cut = s_cut;
+    for (int c = tid; c < (int)M; c += SORT_THREADS) {
+        const unsigned long long key = keys[c];
+        if (key_score(key) >= cut || !(cut > -INFINITY)) surv[atomicAdd(&s_keep, 1u)] = key;
+    }
+    __syncthreads();
+    const int keep = (int)s_keep;                                       // >= k: the k-th largest itself passes the cut
     int K2 = 64;
     while (K2 < keep) K2 <<= 1;
     for (int c = tid; c < K2; c += SORT_THREADS) {
         unsigned long long key = 0ull;
         if (c < keep) {
-            const int id = key_id(keys[c]);
+            const int id = key_id(surv[c]);
             const char* row = reinterpret_cast<const char*>(A.C) + (size_t)id * rb;
             double acc = 0.0;
             for (int v = 0; v < rb / 16; ++v)
                 acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
             key = make_key((float)acc, id);
         }
-        keys[c] = key;
+        keys[c] = key;                                                  // (the scan keys are no longer needed)
     }
     __syncthreads();
     sort_desc(keys, K2, tid);
@@ -703,16 +718,7 @@ int launch_thr_prepare(const ThrArgs& a, hipStream_t st) {
 }
 
 int launch_bound_from_scan(const ThrArgs& a, hipStream_t st) {
-    int cap_pow2 = 64;
-    while (cap_pow2 < a.cap) cap_pow2 <<= 1;
-    const size_t lds = (size_t)cap_pow2 * 8;
-    static bool done[MAX_DEVICES] = {};
-    const int dev = current_device();
-    if (!done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bound_from_scan), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        done[dev] = true;
-    }
-    hipLaunchKernelGGL(k_bound_from_scan, dim3((unsigned)a.nsel), dim3(SORT_THREADS), lds, st, a, cap_pow2);
+    hipLaunchKernelGGL(k_bound_from_scan, dim3((unsigned)a.nsel), dim3(SORT_THREADS), 0, st, a);
     return check_launch("k_bound_from_scan");
 }
 
@@ -720,8 +726,8 @@ int launch_select_all(const ThrArgs& a, hipStream_t st) {
     const int rb = a.d * elem_bytes(a.dtype);
     int cap_pow2 = 64;
     while (cap_pow2 < a.cap) cap_pow2 <<= 1;
-    const size_t lds = (size_t)cap_pow2 * 8 + rb;
-    if (lds > 150 * 1024) { set_error("select_all: candidate capacity %d too large", a.cap); return SSS_EINVAL; }
+    const size_t lds = 2 * (size_t)cap_pow2 * 8 + rb;                 // kept keys + survivors + the query row
+    if (lds > 150 * 1024) { set_error("select_all: candidate capacity %d / row of %d bytes too large", a.cap, rb); return SSS_EINVAL; }
     static bool done[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!done[dev]) {

@@ -34,7 +34,7 @@ AUTO_DECAY_SEARCHES = 64        # clean searches at an escalated level before th
 _LADDER = ("f16", "split", "f32")
 FUSED_MAX_K = 500
 LONG_MAX_K = 4096                                                # sss_ip_topk_long: k <= capacity / 2
-LONG_MAX_D = 8192
+LONG_MAX_ROW_BYTES = 16384
 DTYPE_CODE = {"f32": 0, "bf16": 1}                               # include/sss.h: dtype
 _EXHAUSTIVE_WS_BYTES = 1 << 30
 
@@ -214,7 +214,8 @@ class FlatIndex:
 
     def _long_or_none(self, k: int) -> str:
         """"long": the K-tiled scan for rows beyond the register-resident kernels (``sss_ip_topk_long``)."""
-        return "long" if (self.d % 64 == 0 and self.d <= LONG_MAX_D and k <= LONG_MAX_K) else ""
+        row_bytes = self.d * (4 if self.dtype == "f32" else 2)
+        return "long" if (self.d % 64 == 0 and row_bytes <= LONG_MAX_ROW_BYTES and k <= LONG_MAX_K) else ""
 
     def _scan_served(self, scan: str) -> bool:
         """Does a fused kernel exist for this scan at this d?"""
