@@ -115,6 +115,23 @@ __device__ __forceinline__ double dot_chunk(double acc, const char* qrow, int v,
     return acc;
 }
 
+// Canonical float64 score of ONE stored row by one thread: the row's 16-byte chunks are fetched sixteen at a time
+// (sixteen loads in flight, one memory round trip per 256 bytes instead of one per chunk) and folded into the
+// strictly sequential chain in k order.
+__device__ __forceinline__ double rescore_row(const char* qrow, const char* row, int nchunks, int dtype) {
+    double acc = 0.0;
+    for (int v0 = 0; v0 < nchunks; v0 += 16) {
+        f32x4 c[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (v0 + i < nchunks) c[i] = *reinterpret_cast<const f32x4*>(row + (size_t)(v0 + i) * 16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (v0 + i < nchunks) acc = dot_chunk(acc, qrow, v0 + i, c[i], dtype);
+    }
+    return acc;
+}
+
 __device__ __forceinline__ float elem_to_f32(const void* row, int kk, int dtype) {
     if (dtype == DT_F32) return reinterpret_cast<const float*>(row)[kk];
     const unsigned short b = reinterpret_cast<const unsigned short*>(row)[kk];
@@ -426,11 +443,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
         const unsigned long long key = keys[c];
         const int id = key_id(key);
         double acc = 0.0;
-        if (key != 0 && id >= 0) {
-            const char* row = reinterpret_cast<const char*>(A.C) + (size_t)id * rb;
-            for (int v = 0; v < rb / 16; ++v)
-                acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
-        }
+        if (key != 0 && id >= 0) acc = rescore_row(qrow, reinterpret_cast<const char*>(A.C) + (size_t)id * rb, rb / 16, A.dtype);
         resc[c] = acc;
     }
     __syncthreads();
@@ -585,7 +598,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bound_from_scan(const ThrArgs 
 // superset of every possible result, typically k + a few.  They are re-scored canonically (float64, sequential in
 // k, from the stored rows), bitonic-sorted by (score desc, id asc), the first k written.  status[q] = 0 when the
 // kept rows fit the capacity (and there are at least min(k, n) of them); untouched otherwise.
-__global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, int cap_pow2) {
+// Launched twice: first with a SMALL LDS footprint (`cap_lds` = 2048 keys: several workgroups per CU -- the common
+// case of a few hundred kept rows), then with the full capacity for the queries the first launch had to skip
+// (`second`: resolved queries return at once).
+__global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, int cap_pow2, int second) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);             // [cap_pow2] kept rows (scan keys)
     unsigned long long* surv = keys + cap_pow2;                                          // [cap_pow2] survivors, then exact keys
@@ -600,6 +616,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
     const unsigned M = A.cnt[i];
     const long need = (long)k < (long)A.n ? k : A.n;
     if (M > (unsigned)A.cap || (long)M < need) return;                  // overflow (or NaNs): stays unproven
+    if (M > (unsigned)cap_pow2 || (second && A.status[q] == 0)) return; // the other launch's share
     for (int v = tid; v < rb / 16; v += SORT_THREADS)
         reinterpret_cast<f32x4*>(qrow)[v] = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.Q) + (size_t)q * rb)[v];
     const unsigned long long* ck = A.cand + (size_t)i * A.cap;
@@ -635,10 +652,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
         if (c < keep) {
             const int id = key_id(surv[c]);
             const char* row = reinterpret_cast<const char*>(A.C) + (size_t)id * rb;
-            double acc = 0.0;
-            for (int v = 0; v < rb / 16; ++v)
-                acc = dot_chunk(acc, qrow, v, *reinterpret_cast<const f32x4*>(row + v * 16), A.dtype);
-            key = make_key((float)acc, id);
+            key = make_key((float)rescore_row(qrow, row, rb / 16, A.dtype), id);
         }
         keys[c] = key;                                                  // (the scan keys are no longer needed)
     }
@@ -734,7 +748,9 @@ int launch_select_all(const ThrArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_all), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         done[dev] = true;
     }
-    hipLaunchKernelGGL(k_select_all, dim3((unsigned)a.nsel), dim3(SORT_THREADS), lds, st, a, cap_pow2);
+    const int small = cap_pow2 < 2048 ? cap_pow2 : 2048;
+    hipLaunchKernelGGL(k_select_all, dim3((unsigned)a.nsel), dim3(SORT_THREADS), 2 * (size_t)small * 8 + rb, st, a, small, 0);
+    if (small < cap_pow2) hipLaunchKernelGGL(k_select_all, dim3((unsigned)a.nsel), dim3(SORT_THREADS), lds, st, a, cap_pow2, 1);
     return check_launch("k_select_all");
 }
 
