@@ -6,7 +6,7 @@
 // tile, so the scan is a K-TILED contraction: k_scan_long = 256 queries x 256 corpus rows per workgroup tile,
 // both operands streamed through LDS in 128-byte K slabs (LDS-DMA, double buffered, XOR swizzle on the source
 // address), v_mfma_f32_32x32x16_{f16,bf16} accumulating the full dot products in 8 accumulators per wave
-// (a wave = 32 queries x 256 rows; a lane owns one query column, exactly as in k_scan).
+// (a wave = 64 queries x 128 rows: two B operands x four row blocks; a lane owns one query column per operand).
 //
 // The top-k rides on the THRESHOLD machinery of the rung (select.hip: THRESHOLD RUNG) instead of running lists:
 // the epilogue of a tile only compares its 128 scores per lane with the lane's fixed threshold and appends what
@@ -79,96 +79,120 @@ __global__ __launch_bounds__(512, 2) void k_scan_long(const LongArgs A) {
     if (j_hi > A.tile_count) j_hi = A.tile_count;
     if (j_lo >= j_hi) return;                           // whole workgroup: no barrier below is skipped by part of it
 
-    const int q_glob = g * LT_Q + wave * 32 + r;
-    const float thr = q_glob < nq ? A.thr[q_glob] : INFINITY;   // padding lanes never keep anything
+    // wave layout: 4 query groups of 64 (two MFMA B operands: queries r and 32 + r of the group) x 2 halves of the
+    // row tile (128 rows = four 32-row blocks): every fragment read from LDS feeds two MFMAs (24 ds_read_b128 per
+    // slab and wave for 32 MFMAs; 32 queries x 256 rows per wave would need 36)
+    const int wq = wave & 3, wr = wave >> 2;
+    const int q0 = g * LT_Q + wq * 64 + r, q1 = q0 + 32;
+    const float thr0 = q0 < nq ? A.thr[q0] : INFINITY;          // padding lanes never keep anything
+    const float thr1 = q1 < nq ? A.thr[q1] : INFINITY;
 
     // ---- staging: a slab is [256 rows][128 B] of the corpus tile followed by [256 queries][128 B]; 1 KiB pieces
     // (8 rows x 8 chunks); chunk c of row t sits at chunk slot c ^ ((t >> 1) & 7): with 128-byte rows two rows share
     // a 256-byte bank row, and this key makes every 16-lane group of a ds_read_b128 (16 consecutive rows, one chunk)
-    // cover all 64 banks exactly once.
+    // cover all 64 banks exactly once.  64 pieces per slab: wave w takes pieces w, w + 8, ... -- its first four are
+    // corpus rows, its last four queries; the per-lane source addresses (without the slab offset) are kept in
+    // registers: the queries' for the whole kernel, the rows' per tile.
     const unsigned lds_base = (unsigned)(unsigned long)(lptr_c)smem;
-    const long q_row0 = (long)g * LT_Q;
-    auto stage = [&](int buf, int tile, int slab) __attribute__((always_inline)) {
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        slab = __builtin_amdgcn_readfirstlane(slab);
-        const long c_row0 = (long)tile * LT_ROWS;
-        // 64 pieces per slab: 0..31 corpus rows, 32..63 queries; wave w takes pieces w, w + 8, ...
+    const char* src_q[4];
+    const char* src_c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = ((wave + 8 * i) << 3) + (lane >> 3);       // query row of the tile: pieces 32 + wave + 8 i
+        long row = (long)g * LT_Q + t;
+        if (row > (long)nq - 1) row = (long)nq - 1;             // short query batch: clamp
+        src_q[i] = Qb + (size_t)row * rb + ((lane & 7) ^ ((t >> 1) & 7)) * 16;
+    }
+    auto set_tile = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = ((wave + 8 * i) << 3) + (lane >> 3);   // corpus row of the tile: pieces wave + 8 i
+            long row = (long)tile * LT_ROWS + t;
+            if (row > (long)n - 1) row = (long)n - 1;           // ragged last tile: clamp
+            src_c[i] = Cb + (size_t)row * rb + ((lane & 7) ^ ((t >> 1) & 7)) * 16;
+        }
+    };
+    auto stage = [&](int buf, int slab) __attribute__((always_inline)) {
+        const size_t so = (size_t)slab * LT_BK;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int p = wave + 8 * i;                         // wave-uniform
-            const bool is_q = p >= 32;
-            const int t = ((p & 31) << 3) + (lane >> 3);        // row of the (corpus | query) tile
-            const int c = (lane & 7) ^ ((t >> 1) & 7);
-            long row = (is_q ? q_row0 : c_row0) + t;
-            const long last = (is_q ? (long)nq : (long)n) - 1;
-            if (row > last) row = last;                         // ragged tile / short query batch: clamp
-            const char* src = (is_q ? Qb : Cb) + (size_t)row * rb + (size_t)slab * LT_BK + c * 16;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * LT_STAGE + p * 1024);
-            // (per-lane 64-bit source address: rows are up to 6400 bytes apart, tiles up to gigabytes)
+            const char* src = (i < 4 ? src_c[i & 3] : src_q[i & 3]) + so;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * LT_STAGE + ((i < 4 ? 0 : 32) + wave + 8 * (i & 3)) * 1024);
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                          : : "v"(src), "s"(dst) : "memory");
         }
     };
 
     const f32x16 zero = {0};
-    f32x16 acc[8];
-    const int keyq = ((wave * 32 + r) >> 1) & 7;                // swizzle key of this lane's query row
+    f32x16 acc[4][2];
+    const int keyq0 = ((wq * 64 + r) >> 1) & 7, keyq1 = ((wq * 64 + 32 + r) >> 1) & 7;
     const int total_steps = (j_hi - j_lo) * nslab;             // slab steps of this split
     auto tile_of = [&](int j) __attribute__((always_inline)) { return (int)((long)j * A.total_tiles / A.tile_count); };
 
-    stage(0, tile_of(j_lo), 0);
+    set_tile(tile_of(j_lo));
+    stage(0, 0);
     int step = 0;
     for (int j = j_lo; j < j_hi; ++j) {
         const int tile = tile_of(j);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) acc[b] = zero;
+        for (int b = 0; b < 4; ++b) { acc[b][0] = zero; acc[b][1] = zero; }
         for (int s = 0; s < nslab; ++s, ++step) {
             const int buf = step & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current slab have landed
             __syncthreads();                                    // ... everyone's have, and the other buffer is free
             if (step + 1 < total_steps) {
-                const bool next_tile = s + 1 == nslab;
-                stage(buf ^ 1, next_tile ? tile_of(j + 1) : tile, next_tile ? 0 : s + 1);
+                if (s + 1 == nslab) { set_tile(tile_of(j + 1)); stage(buf ^ 1, 0); }
+                else stage(buf ^ 1, s + 1);
             }
             const char* rows = smem + buf * LT_STAGE;
             const char* qs = rows + LT_ROWS * LT_BK;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int cq = (2 * u + h) ^ keyq;
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(qs + (wave * 32 + r) * LT_BK + cq * 16);
-                f32x4 a[8];
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(qs + (wq * 64 + r) * LT_BK + ((2 * u + h) ^ keyq0) * 16);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(qs + (wq * 64 + 32 + r) * LT_BK + ((2 * u + h) ^ keyq1) * 16);
+                f32x4 a[4];
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const int t = b * 32 + r;
-                    const int c = (2 * u + h) ^ ((t >> 1) & 7);
-                    a[b] = *reinterpret_cast<const f32x4*>(rows + t * LT_BK + c * 16);
+                for (int b = 0; b < 4; ++b) {
+                    const int t = wr * 128 + b * 32 + r;
+                    a[b] = *reinterpret_cast<const f32x4*>(rows + t * LT_BK + ((2 * u + h) ^ ((t >> 1) & 7)) * 16);
                 }
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    if constexpr (DT == DT_F16)
-                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[b]), __builtin_bit_cast(f16x8, bq), acc[b], 0, 0, 0);
-                    else
-                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[b]), __builtin_bit_cast(bf16x8, bq), acc[b], 0, 0, 0);
+                for (int b = 0; b < 4; ++b) {
+                    if constexpr (DT == DT_F16) {
+                        acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[b]), __builtin_bit_cast(f16x8, b0), acc[b][0], 0, 0, 0);
+                        acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[b]), __builtin_bit_cast(f16x8, b1), acc[b][1], 0, 0, 0);
+                    } else {
+                        acc[b][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[b]), __builtin_bit_cast(bf16x8, b0), acc[b][0], 0, 0, 0);
+                        acc[b][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[b]), __builtin_bit_cast(bf16x8, b1), acc[b][1], 0, 0, 0);
+                    }
                 }
             }
         }
-        // ---- tile epilogue: acc[b][jj] is (corpus row tile * 256 + 32 b + (jj & 3) + 8 (jj >> 2) + 4 h, query r)
-        float m = -INFINITY;
+        // ---- tile epilogue: acc[b][s][jj] is (corpus row tile * 256 + 128 wr + 32 b + (jj & 3) + 8 (jj >> 2) + 4 h,
+        // query r (s = 0) / 32 + r (s = 1) of the wave's 64)
+        float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < 4; ++b) {
 #pragma unroll
-            for (int jj = 0; jj < 16; jj += 2) m = vmax3(m, acc[b][jj], acc[b][jj + 1]);
+            for (int jj = 0; jj < 16; jj += 2) {
+                m0 = vmax3(m0, acc[b][0][jj], acc[b][0][jj + 1]);
+                m1 = vmax3(m1, acc[b][1][jj], acc[b][1][jj + 1]);
+            }
         }
-        if (__builtin_amdgcn_ballot_w64(m > thr) != 0) {
-            const int row_base = tile * LT_ROWS + 4 * h;
+        if (__builtin_amdgcn_ballot_w64(m0 > thr0 || m1 > thr1) != 0) {
+            const int row_base = tile * LT_ROWS + wr * 128 + 4 * h;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
+            for (int b = 0; b < 4; ++b) {
 #pragma unroll
                 for (int jj = 0; jj < 16; ++jj) {
                     const int row = row_base + 32 * b + (jj & 3) + 8 * (jj >> 2);
-                    if (acc[b][jj] > thr && row < n) {
-                        const unsigned pos = atomicAdd(A.cnt + q_glob, 1u);
-                        if (pos < (unsigned)A.cap) A.cand[(size_t)q_glob * A.cap + pos] = make_key(acc[b][jj], row);
+                    if (acc[b][0][jj] > thr0 && row < n) {
+                        const unsigned pos = atomicAdd(A.cnt + q0, 1u);
+                        if (pos < (unsigned)A.cap) A.cand[(size_t)q0 * A.cap + pos] = make_key(acc[b][0][jj], row);
+                    }
+                    if (acc[b][1][jj] > thr1 && row < n) {
+                        const unsigned pos = atomicAdd(A.cnt + q1, 1u);
+                        if (pos < (unsigned)A.cap) A.cand[(size_t)q1 * A.cap + pos] = make_key(acc[b][1][jj], row);
                     }
                 }
             }
