@@ -497,3 +497,25 @@ def test_feature_ids_are_range_checked(cuda):
             enc.prepare_actions(bad)
         with pytest.raises(IndexError):
             enc.prepare(S.build_batch(bad).to(cuda))
+
+
+def test_cooperative_query_embedding_slices_equal_the_full_batch(cuda):
+    """Multi-GPU query embedding (distributed.query_slice / gather_query_embeddings): every rank embeds nq / world of
+    the query sessions and an all-gather concatenates them.  Sessions are independent graphs (self_loop_rule
+    "none"), so the concatenation must equal -- bit for bit -- the embedding of the whole batch on one rank.  The
+    ranks are played one after the other on this GPU; the collective itself is covered by tests/test_distributed_cpu.py."""
+    from sessionsimilaritysearch_amd.distributed import gather_query_embeddings, query_slice
+    cfg = EncoderConfig(d_in=128, h=128, n_layers=2, d_out=128, n_items=5000, n_query=257, self_loop_rule="none")
+    enc = SessionEncoder(cfg, init_weights(cfg, 31), cuda)
+    nq = 1024
+    acts = S.synthetic_actions(nq, 20269999, cfg.n_items, cfg.n_query)
+    full = enc(enc.prepare_actions(acts), l2_normalize=True)
+    for world in (2, 4, 8):
+        parts = []
+        for rank in range(world):
+            lo, hi = query_slice(nq, world, rank)
+            assert hi - lo == nq // world
+            parts.append(enc(enc.prepare_actions(acts.slice(lo, hi)), l2_normalize=True))
+        assert torch.equal(torch.cat(parts), full)
+    assert query_slice(1000, 3, 1) == (0, 1000)            # world does not divide nq: every rank embeds everything
+    assert gather_query_embeddings(full, nq) is full       # single process: nothing to gather
