@@ -25,6 +25,7 @@ namespace sss {
 
 constexpr int FS_CAP = 2048;       // candidates a wave stages in LDS (more -> unproven)
 constexpr int FS_K2 = 32;          // candidates the wave-per-query kernel can re-score (its second chance widens K2 <= 16 up to this)
+constexpr int FS_COL = 16;         // candidate keys a lane keeps in registers (64 x 16 = 1024 candidates; more -> columns in LDS)
 constexpr int SEL_MAX_K2 = 512;
 constexpr int SORT_THREADS = 256;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -267,23 +268,47 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
         clear_state(A, q, lane, 64);
         return;
     }
-    // ---- stage keys and the query row; per-lane best of keys lane, lane+64, ...
+    // ---- the query row, and this lane's COLUMN of the candidate keys (keys lane, lane + 64, ...).  Up to 1024
+    // candidates (the usual few hundred) a column is 16 keys in registers, sorted once by a bitonic network: a
+    // selection round is then one wave-wide maximum of the column heads and a register shift in the owner lane.
+    // More candidates: columns stay in LDS and the owner rescans its column after every round (as in round 2,
+    // when this was the only form and the 16 rounds took 40 % of the kernel).
     const unsigned long long* ck = A.cand + (size_t)q * A.cap;
+    const bool in_regs = M <= 64 * FS_COL;                        // wave-uniform
+    unsigned long long col[FS_COL];
     unsigned long long best = 0; int bidx = -1;
-    for (int i = lane; i < M; i += 64) {
-        const unsigned long long v = ck[i];
-        keys[i] = v;
-        if (v > best) { best = v; bidx = i; }
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < FS_COL; ++j) col[j] = lane + 64 * j < M ? ck[lane + 64 * j] : 0ull;
+#pragma unroll
+        for (int kk = 2; kk <= FS_COL; kk <<= 1)
+#pragma unroll
+            for (int jj = kk >> 1; jj > 0; jj >>= 1)
+#pragma unroll
+                for (int x = 0; x < FS_COL; ++x) {
+                    const int y = x ^ jj;
+                    if (y > x) {
+                        const unsigned long long a = col[x], b = col[y];
+                        const bool sw = ((x & kk) == 0) ? a < b : a > b;      // descending overall
+                        col[x] = sw ? b : a; col[y] = sw ? a : b;
+                    }
+                }
+        best = col[0];
+    } else {
+        for (int i = lane; i < M; i += 64) {
+            const unsigned long long v = ck[i];
+            keys[i] = v;
+            if (v > best) { best = v; bidx = i; }
+        }
     }
-    for (int i = lane; i < rb / 16; i += 64)
-        reinterpret_cast<f32x4*>(qrow)[i] = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.Q) + (size_t)q * rb)[i];
-    if (lane == 0) { *s_nvalid = 0; *s_kth = 0.0; }
-    wave_sync();
-    // ---- K2 rounds: wave-wide arg-max, the owner lane retires its key and rescans its column
-    for (int it = 0; it < K2; ++it) {
-        const unsigned long long w = wave_max_u64(best);
-        if (lane == 0) sel[it] = w;
-        if (w != 0 && best == w) {                                // keys of real candidates are unique
+    // the owner of the round's maximum retires it: its next-best key becomes its column head
+    auto retire = [&]() __attribute__((always_inline)) {
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j + 1 < FS_COL; ++j) col[j] = col[j + 1];
+            col[FS_COL - 1] = 0ull;
+            best = col[0];
+        } else {
             keys[bidx] = 0;
             best = 0; bidx = -1;
             for (int i = lane; i < M; i += 64) {
@@ -291,6 +316,16 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
                 if (v > best) { best = v; bidx = i; }
             }
         }
+    };
+    for (int i = lane; i < rb / 16; i += 64)
+        reinterpret_cast<f32x4*>(qrow)[i] = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.Q) + (size_t)q * rb)[i];
+    if (lane == 0) { *s_nvalid = 0; *s_kth = 0.0; }
+    wave_sync();
+    // ---- K2 rounds: wave-wide arg-max, the owner lane retires its key
+    for (int it = 0; it < K2; ++it) {
+        const unsigned long long w = wave_max_u64(best);
+        if (lane == 0) sel[it] = w;
+        if (w != 0 && best == w) retire();                        // keys of real candidates are unique
     }
     wave_sync();
     // ---- float64 re-score: one lane per candidate walks its corpus row (16-byte loads straight from
@@ -354,14 +389,7 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
                 break;
             }
             if (lane == 0) sel[K2x] = w;
-            if (best == w) {
-                keys[bidx] = 0;
-                best = 0; bidx = -1;
-                for (int i = lane; i < M; i += 64) {
-                    const unsigned long long v = keys[i];
-                    if (v > best) { best = v; bidx = i; }
-                }
-            }
+            if (best == w) retire();
         }
         if (K2x == FS_K2) open_end = true;
         wave_sync();
