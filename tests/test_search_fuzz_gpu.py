@@ -11,13 +11,13 @@ pytestmark = pytest.mark.gpu
 
 
 def _case(rng):
-    d = int(rng.choice([64, 128, 128, 256, 512, 96]))
+    d = int(rng.choice([64, 128, 128, 256, 512, 96, 320, 1600]))        # 320 / 1600: the K-tiled long-row scan
     scans = ["auto", "f32", "split", "f16"] if d in (64, 128, 256) else ["auto", "f16"] if d == 512 else ["auto"]
     n = int(rng.choice([1, 37, 1000, 4097, 30000, 70001]))
-    return dict(d=d, scan=str(rng.choice(scans)), n=n if d < 256 else min(n, 30000),
+    return dict(d=d, scan=str(rng.choice(scans)), n=n if d < 256 else min(n, 30000) if d < 1600 else min(n, 4097),
                 nq=int(rng.choice([1, 31, 64, 257, 600])), k=int(rng.choice([1, 5, 10, 12, 13, 16, 17, 20, 21, 50, 100, 200])),
                 flavour=str(rng.choice(["unit", "unit", "raw", "scaled", "dups", "adds"])),
-                bf16=bool(d in (128, 256, 512) and rng.random() < 0.2))
+                bf16=bool(d in (128, 256, 512, 320) and rng.random() < 0.2))
 
 
 @pytest.mark.parametrize("seed", [101, 202, 303])
