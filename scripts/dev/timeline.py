@@ -1,5 +1,5 @@
 """Dev helper (not product): per-workgroup timeline of k_scan from a -DSSS_TIMELINE build of libsss
-(scripts/dev/libsss_tl.so, built by hand: see DESIGN.md "in-kernel stamps").  Usage: timeline.py nq n d k"""
+(scripts/dev/libsss_tl.so: see make_timeline_src.py).  Usage: timeline.py nq n d k"""
 import sys, os, ctypes, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -22,11 +22,12 @@ for _ in range(20):
 torch.cuda.synchronize()
 L = _lib.lib()
 nwg = 256
-buf = (ctypes.c_ulonglong * (nwg * 8))()
+W = 16
+buf = (ctypes.c_ulonglong * (nwg * W))()
 fn = L.sss_debug_timeline
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
-rc = fn(buf, nwg * 8)
-a = np.array(buf, dtype=np.uint64).reshape(nwg, 8).astype(np.int64)
+rc = fn(buf, nwg * W)
+a = np.array(buf, dtype=np.uint64).reshape(nwg, W).astype(np.int64)
 rt0, rt1 = a[:, 0], a[:, 7]
 t = a[:, 1:6]
 start_skew_us = (rt0 - rt0.min()) / 100.0
@@ -41,4 +42,22 @@ print(json.dumps(dict(rc=rc, nq=nq, n=n, d=d, k=k, scan=scan,
     clock_ghz_med=float(np.median(ghz)),
     prologue_cyc_med=float(np.median(t[:, 2] - t[:, 0])), loop_cyc_med=float(np.median(t[:, 3] - t[:, 2])),
     loop_cyc_min=float((t[:, 3] - t[:, 2]).min()), loop_cyc_max=float((t[:, 3] - t[:, 2]).max()),
-    tail_cyc_med=float(np.median(t[:, 4] - t[:, 3])), rare_med=float(np.median(a[:, 6])), rare_max=int(a[:, 6].max()))))
+    tail_cyc_med=float(np.median(t[:, 4] - t[:, 3])),
+    boot_done_cyc_med=float(np.median(a[:, 8] - t[:, 2])), loop_start_us_med=float(np.median((a[:, 9] - rt0.min()) / 100.0)), rare_cyc_med=float(np.median(a[:, 10])), rare_med=float(np.median(a[:, 6])), rare_max=int(a[:, 6].max()))))
+
+tb = (ctypes.c_ulonglong * 192)()
+L.sss_debug_tiles.argtypes = [ctypes.c_void_p]
+L.sss_debug_tiles(tb)
+tt = np.array(tb, dtype=np.uint64).astype(np.int64)
+for o in (0, 96):
+    v = tt[o:o + 96]; v = v[v > 0]
+    print("tile-end deltas (cycles) wg", 0 if o == 0 else 101, ":", (v[0] - a[0 if o == 0 else 101, 3]), list(np.diff(v))[:70])
+
+wb = (ctypes.c_ulonglong * 288)()
+L.sss_debug_w.argtypes = [ctypes.c_void_p]
+L.sss_debug_w(wb)
+w = np.array(wb, dtype=np.uint64).astype(np.int64)
+nt = int((tt[:96] > 0).sum())
+print("wg 0 wave 0 per tile: vmcnt wait", list(w[:nt])[:40])
+print("wg 0 wave 0 per tile: barrier wait", list(w[96:96 + nt])[:40])
+print("wg 0 wave 0 per tile: rare cycles", list(np.diff(np.concatenate([[0], w[192:192 + nt]])))[:40])

@@ -84,8 +84,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     const int q_glob = g * WGQ + q_local;
     int q_ld = q_glob < nq ? q_glob : nq - 1;
     if constexpr (THR) q_ld = A.qsel[q_ld];             // row of Q this lane's (compact) query lives in
-    f32x4 qc[NU];
-    load_queries<RB, DT>(Qb, q_ld, h, qc);
+    f32x4 qc[NU];                                       // (loaded after the first tiles' DMA has been issued, below)
 
     // Lane list, sorted descending; empty slots are (-inf, -1).  thr = max(list tail, tau) is the
     // one value the hot path compares against.
@@ -111,10 +110,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     // and again at the last iteration (lists live)
     auto tile_of = [&](int i) { return (boot && i == ntiles) ? tile_lo : tile_lo + i; };
 
+    unsigned cls_byte = 0;                       // byte offset of this lane's class inside its query's 64 B of slots
+    bool slots_seen = false;                     // the LDS copy of the slots has been filled at least once
     unsigned* my_slot = nullptr;
+    unsigned* my_mirror = nullptr;              // second slot of this class when fewer classes than slots (scan.h: Ju)
     const unsigned* my_half = nullptr;
     if (use_tau) {
-        my_slot = A.slots + (size_t)q_ld * J + (unsigned)(2 * split + h) % (unsigned)J;
+        const unsigned cls = (unsigned)(2 * split + h) % (unsigned)A.Ju;
+        cls_byte = cls * 4u;
+        my_slot = A.slots + (size_t)q_ld * J + cls;
+        if ((int)cls + A.Ju < J) my_mirror = my_slot + A.Ju;
         my_half = A.slots + (size_t)q_ld * J + h * (J >> 1);
     }
     // min over the query's J slots.  Synchronous form (bootstrap wait; J > 16): each lane of the
@@ -165,8 +170,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             val = c == 2 ? v2 : c == 4 ? v4 : c == 8 ? v8 : v16;
             ok = (c == 2 ? i2 : c == 4 ? i4 : c == 8 ? i8 : i16) >= 0;
         }
-        if (ok && val > pub && val > tau && q_glob < nq) {     // at or below tau it cannot raise the minimum
+        // A lane's new best only matters if it beats its CLASS's best -- which ~10 lists share, so most lane records
+        // are not class records.  The last fetched copy of the slots (LDS, J == 16) tells: without this filter the
+        // early tiles, where every lane sets records all the time, spend most of their time waiting for some
+        // hundred agent-scope atomics per query line to drain (vmcnt(0) at the end of the tile).
+        unsigned cur = 0u;
+        if (J == 16 && slots_seen) cur = *reinterpret_cast<const unsigned*>(smem + TAU_LDS + wave * 2048 + r * 64 + cls_byte);
+        if (ok && val > pub && val > tau && f2ord(val) > cur && q_glob < nq) {     // at or below tau it cannot raise the minimum
             __hip_atomic_fetch_max(my_slot, f2ord(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (my_mirror) __hip_atomic_fetch_max(my_mirror, f2ord(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pub = val;
         }
     };
@@ -326,7 +338,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             }
         }
     };
+    // Prologue: the first TWO tiles' DMA goes out before anything else (both buffers are free; from a cold start a tile
+    // takes ~4 us to land, far longer than the bootstrap tile takes to scan), then the query rows are fetched and
+    // converted under it.
+    const bool two_ahead = H > 1 && niter > 1;          // (H == 1 issues a tile's successor before its MFMAs anyway)
     if (ntiles > 0) stage(0, tile_lo);
+    if (two_ahead) stage(1, tile_of(1));
+    load_queries<RB, DT>(Qb, q_ld, h, qc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -360,8 +378,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     auto tile_end = [&](int i) {
         const bool pre = boot && i == 0;
         if (pre) publish();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile landed
-        if (use_tau && J == 16 && i > 0 && refresh_at(i)) set_tau(tau_read());   // ... and so did its slots (own region: no barrier needed)
+        // this wave's share of the next tile landed (after the bootstrap tile: its own atomics did -- skipping this wait
+        // there only moves it into the polling loop below, measured slower)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (use_tau && J == 16 && i > 0 && refresh_at(i)) { set_tau(tau_read()); slots_seen = true; }   // ... and so did its slots (own region: no barrier needed)
         __syncthreads();                                   // ... everyone's did, and this buffer is free
         if (pre) {
             // Wait (bounded) until every class of this wave's queries has published its bootstrap
@@ -382,7 +402,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     auto score_step = [&](int t) -> float {
         const int i = (int)((unsigned)t / (unsigned)H), sub = (int)((unsigned)t % (unsigned)H);   // (unsigned: shifts, not the signed-division sequence)
         if (sub == 0) tile_top(i);
-        const int next_tile = (i + 1 < niter) ? tile_of(i + 1) : -1;
+        const int next_tile = (i + 1 < niter && !(two_ahead && i == 0)) ? tile_of(i + 1) : -1;
         mfma_sub(i & 1, sub, next_tile);
         row0_of_step = (long)tile_of(i) * TR + sub * 64;
         if (row0_of_step + 64 > n) {                        // wave-uniform, last tile only
@@ -475,9 +495,12 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     p.tile_rows = tr;
     p.S = S;
     p.L = 2 * S;
-    // k <= 16: K2 = 16 (class maxima + bootstrap; the select kernel's second chance widens the candidate set
-    // where the slack K2 - k is too thin for a query); larger k: k + 12
-    p.K2 = k <= KP ? KP : k + 12;
+    // k <= 14: K2 = max(k + 2, 8) (class maxima + bootstrap; the select kernel's second chance widens the candidate
+    // set where the slack K2 - k is too thin for a query -- as it always had to for k = 15, 16, where K2 = 16 = KP
+    // leaves none); larger k: k + 12.  A small K2 pays twice: the shared threshold certifies only K2 rows, and
+    // "min over K2 class maxima" sits nearer the top the fewer classes there are (it tracks roughly the 35th best
+    // row seen with 12 classes, the 50th with 16): a third fewer candidates to insert, re-score and carry.
+    p.K2 = k + 2 <= KP ? (k + 2 < 8 ? 8 : k + 2) : k <= KP ? KP : k + 12;
     if ((long)p.L * KP < p.K2) p.K2 = p.L * KP;
     p.total_tiles = (int)((n + tr - 1) / tr);
     p.tiles_per_split = (p.total_tiles + S - 1) / S;
@@ -491,7 +514,10 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     p.J = p.K2 <= 128 ? 16 : 64;
     p.cert = 1;
     while (p.J * p.cert < p.K2 && p.cert < KP) p.cert *= 2;
-    if (p.J * p.cert < p.K2 || 2 * active_splits < p.J) p.J = 0;      // tiny corpus: no threshold
+    // K2 < 16: only Ju = K2 distinct classes; slots Ju .. 15 mirror classes 0 .. 15 - Ju (their publishers write both),
+    // so that "min over the 16 slots" -- what every reader computes -- IS the min over the Ju class maxima
+    p.Ju = (p.cert == 1 && p.K2 < p.J) ? p.K2 : p.J;
+    if (p.J * p.cert < p.K2 || 2 * active_splits < p.Ju) { p.J = 0; p.Ju = 0; }      // tiny corpus: no threshold
     p.boot = (p.J > 0 && p.cert == 1) ? 1 : 0;
     p.total_bytes = align256((size_t)nq * p.cap * 8);
     return p;

@@ -86,7 +86,7 @@ def test_random_data_is_proven_exact_without_fallback(cuda, scan):
 
 @pytest.mark.parametrize("k", [12, 13, 16, 20, 21, 33])
 def test_every_k_regime_is_proven_on_random_data(cuda, scan, k):
-    """k <= 16 (K2 = 16: class maxima + bootstrap, wave-per-query select whose second chance supplies the
+    """k <= 16 (K2 = max(k + 2, 8) up to 16: class maxima + bootstrap, wave-per-query select whose second chance supplies the
     slack for k = 13..16), 17..116 (cert-th best per class, sort-based select) -- no regime may lean on the
     exhaustive fallback for ordinary data."""
     rng = np.random.default_rng(100 + k)
