@@ -32,7 +32,7 @@ stats bench_c5_bf16 bench.py --steps 10 --warmup 2 --no-cpu-baseline --corpus-ro
 stats bench_c3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload c3 --corpus-rows 1000000
 stats encoder scripts/bench_encoder.py 1024
 stats search_shapes scripts/quick_search_bench.py 1024,125000,128,10,f16 1024,1000000,128,10,f16 1024,10000000,128,10,f16 1024,1000000,256,10,f16 1024,125000,128,10,split 1024,1000000,128,10,split 1024,1000000,64,10,split 1024,1000000,128,100,split 1024,125000,128,10,f32mfma 1024,1000000,128,10,f32mfma 1024,125000,64,10,f32mfma 1024,125000,128,100,f32mfma 1024,1000000,1600,100 200,1000000,1600,100 1024,1000000,1600,10 1024,100000,1600,100
-PM="bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+PM="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-reference-shapes"
 pmc pmc_fetch FETCH_SIZE $PM
 pmc pmc_write WRITE_SIZE $PM
 pmc pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" $PM
