@@ -1,5 +1,6 @@
-"""Dev helper: times sss_linear (k_linear_f32, per-op path) against sss_linear_grouped (fused path's GEMM) on corpus-build
-shapes and on the reference model's shapes.  ab_linear.py [ref]"""
+"""Dev helper: times sss_linear_grouped and sss_linear (since round 3 the same kernel: one problem of the grouped GEMM) on
+corpus-build shapes and on the reference model's shapes, with the vendor library's f32 GEMM (torch.mm) as a yardstick
+(DESIGN.md section 5.2).  ab_linear.py [ref]"""
 import sys, os, torch, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sessionsimilaritysearch_amd import _lib
@@ -22,4 +23,7 @@ for (n, m, k) in shapes:
     us_g = timeit(lambda: L.sss_linear_grouped(arr, 1, k, st))
     us_f = timeit(lambda: L.sss_linear(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), 0, y2.data_ptr(), y2.stride(0), n, m, k, st))
     same = bool(torch.equal(y, y2))
-    print(f"n={n} m={m} k={k}: grouped {us_g:.1f} us {2.0*n*m*k/us_g/1e6:.1f} TFLOP/s | per-op {us_f:.1f} us {2.0*n*m*k/us_f/1e6:.1f} TFLOP/s | identical {same}", flush=True)
+    us_t = timeit(lambda: torch.mm(x, w.t(), out=y2))          # yardstick only: the vendor library's f32 GEMM
+    err = float((y - y2).abs().max() / y.abs().max())
+    print(f"n={n} m={m} k={k}: grouped {us_g:.1f} us {2.0*n*m*k/us_g/1e6:.1f} TFLOP/s | per-op {us_f:.1f} us {2.0*n*m*k/us_f/1e6:.1f} TFLOP/s | identical {same} | "
+          f"library {us_t:.1f} us {2.0*n*m*k/us_t/1e6:.1f} TFLOP/s (rel diff {err:.1e})", flush=True)

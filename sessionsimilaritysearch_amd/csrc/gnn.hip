@@ -1,7 +1,7 @@
 // Session-encoder kernels (gfx950): HeteroGGNN message passing + positional-attention pooling.
 //
 // Reference ops replaced (op semantics Appendix A):
-//   k_linear_f32        <- the dense node transforms inside PyG GATConv (lin_src), GatedGraphConv
+//   k_linear_grouped    <- the dense node transforms inside PyG GATConv (lin_src), GatedGraphConv
 //                          (x @ weight), torch GRUCell (W_ih, W_hh) and the nn.Linear layers of
 //                          PositionalAttentionPooling (reference model/gnn.py:54,58,186-190)
 //   k_gat_aggregate     <- GATConv.propagate: leaky_relu(0.2) + per-target softmax + weighted sum
@@ -17,81 +17,9 @@
 
 namespace sss {
 
-// ------------------------------------------------------------------------------------------
-// Y[N, M] = X[N, K] * W[M, K]^T (+ bias[M]).  64 x 64 block tile, 4 waves of 32 x 32 (one MFMA
-// tile each), K consumed in chunks of up to 128 staged ONCE per chunk through LDS (register
-// staged, 16 float4 loads in flight per thread), 16-byte chunk XOR swizzle -> conflict-free
-// ds_read_b128.  The encoder's shapes are K = 64..384 with a few thousand rows per query batch:
-// per-workgroup latency, not FLOPs, bounds them, so the K loop is 1-3 steps and two workgroups
-// share a CU (64 KiB LDS each).
-constexpr int LT = 64;      // tile rows (X) and columns (W rows)
+constexpr int LT = 64;      // GEMM tile rows (X) and columns (W rows): see k_linear_grouped below
 
-template <int KC>           // K chunk: 128, 64 or 32 (K % KC == 0)
-__global__ __launch_bounds__(256, 2) void k_linear_f32(const float* __restrict__ X, long ldx,
-                                                       const float* __restrict__ W, long ldw,
-                                                       const float* __restrict__ bias, float* __restrict__ Y,
-                                                       long ldy, long N, int M, int K) {
-    constexpr int CPR = KC / 4;                 // 16-byte chunks per staged row
-    constexpr int NLD = LT * CPR / 256;         // float4 loads per thread per operand (8, 4, 2)
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];        // [X|W][64 rows][32 chunks]
-    float* lx = lds_raw;
-    float* lw = lds_raw + LT * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
-    const long row0 = (long)blockIdx.x * LT;
-    const int col0 = blockIdx.y * LT;
-    const int xr = wr * 32 + r, wrow = wc * 32 + r;
-
-    f32x16 acc = {0};
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        f32x4 sx[NLD], sw[NLD];          // ext-vector type: stays in VGPRs (HIP's float4 struct array went to scratch)
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int p = tid + 256 * i;
-            const int tr = p / CPR, c = p % CPR;
-            long gr = row0 + tr; if (gr > N - 1) gr = N - 1;
-            int gw = col0 + tr; if (gw > M - 1) gw = M - 1;
-            sx[i] = *reinterpret_cast<const f32x4*>(X + gr * ldx + k0 + c * 4);
-            sw[i] = *reinterpret_cast<const f32x4*>(W + (long)gw * ldw + k0 + c * 4);
-        }
-        if (k0 > 0) __syncthreads();                         // previous chunk fully consumed
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int p = tid + 256 * i;
-            const int tr = p / CPR, c = p % CPR;
-            const int cs = c ^ (tr & 15);                    // rows are 32 chunks apart: stays in the row
-            *reinterpret_cast<f32x4*>(lx + (tr * 32 + cs) * 4) = sx[i];
-            *reinterpret_cast<f32x4*>(lw + (tr * 32 + cs) * 4) = sw[i];
-        }
-        __syncthreads();
-        float4 a = *reinterpret_cast<const float4*>(lx + (xr * 32 + (h ^ (xr & 15))) * 4);
-        float4 b = *reinterpret_cast<const float4*>(lw + (wrow * 32 + (h ^ (wrow & 15))) * 4);
-#pragma unroll
-        for (int u = 0; u < KC / 8; ++u) {
-            float4 na = a, nb = b;
-            if (u + 1 < KC / 8) {                            // fragments one k-group ahead
-                na = *reinterpret_cast<const float4*>(lx + (xr * 32 + ((2 * u + 2 + h) ^ (xr & 15))) * 4);
-                nb = *reinterpret_cast<const float4*>(lw + (wrow * 32 + ((2 * u + 2 + h) ^ (wrow & 15))) * 4);
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-            a = na; b = nb;
-        }
-    }
-    // C/D map of 32x32: col = lane & 31 (W row), row = (j & 3) + 8 * (j >> 2) + 4 * h (X row)
-    const int col = col0 + wc * 32 + r;
-    if (col < M) {
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const long row = row0 + wr * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-            if (row < N) Y[row * ldy + col] = acc[j] + bv;
-        }
-    }
-}
+int linear_grouped(LinBatch& b, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
 // Per target node i (CSR by target): e_ij = leaky_relu(as[j] + ad[i], 0.2);
@@ -335,6 +263,8 @@ static unsigned grid_rows(long n, int lpr) {
         default: { constexpr int L = 64; CALL; } break; \
     }
 
+// Y[N, M] = X[N, K] * W[M, K]^T (+ bias[M]): one problem of the grouped kernel (round 3: the separate 64 x 64
+// kernel this entry point used to launch computed the identical fma chains 8-20 % slower on every shape).
 int linear_f32(const float* X, long ldx, const float* W, long ldw, const float* bias, float* Y, long ldy,
                long N, int M, int K, hipStream_t st) {
     if (N < 0 || M <= 0 || K <= 0 || K % 32 || ldx % 4 || ldw % 4 || ldx < K || ldw < K || ldy < M) {
@@ -342,23 +272,12 @@ int linear_f32(const float* X, long ldx, const float* W, long ldw, const float* 
         return SSS_EINVAL;
     }
     if (N == 0) return SSS_OK;
-    dim3 grid((unsigned)((N + LT - 1) / LT), (unsigned)((M + LT - 1) / LT));
-    const int lds = 2 * LT * 128 * 4;
-    static bool attr_done[MAX_DEVICES] = {};
-    const int dev = current_device();
-    if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_f32<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_f32<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_f32<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done[dev] = true;
-    }
-    if (K % 128 == 0)
-        hipLaunchKernelGGL(k_linear_f32<128>, grid, dim3(256), lds, st, X, ldx, W, ldw, bias, Y, ldy, N, M, K);
-    else if (K % 64 == 0)
-        hipLaunchKernelGGL(k_linear_f32<64>, grid, dim3(256), lds, st, X, ldx, W, ldw, bias, Y, ldy, N, M, K);
-    else
-        hipLaunchKernelGGL(k_linear_f32<32>, grid, dim3(256), lds, st, X, ldx, W, ldw, bias, Y, ldy, N, M, K);
-    return check_launch("k_linear_f32");
+    LinBatch b = {};
+    b.nprob = 1; b.K = K;
+    LinProb& p = b.p[0];
+    p.x = X; p.ldx = ldx; p.ids = nullptr; p.table = nullptr; p.xcopy = nullptr; p.ld_xcopy = 0;
+    p.w = W; p.ldw = ldw; p.bias = bias; p.y = Y; p.ldy = ldy; p.n = N; p.m = M; p.act = 0;
+    return linear_grouped(b, st);
 }
 
 int gat_aggregate(const float* xs, long ld_xs, const float* a_src, long ld_as, const float* a_dst, long ld_ad,
@@ -922,6 +841,7 @@ int linear_grouped(LinBatch& b, hipStream_t st) {
     // query-batch launch is resident at once and the load / MFMA / store phases of different workgroups
     // overlap (these launches are latency-bound, not FLOP-bound; measured against 64- and 128-chunks)
     const int lds32 = 2 * LT * 8 * 16;
+    // (chunks of 64 on deep, chip-filling problems -- corpus build, the reference's 768 / 800-wide layers -- measured the same)
     hipLaunchKernelGGL(k_linear_grouped<32>, dim3((unsigned)total), dim3(256), lds32, st, b);
     return check_launch("k_linear_grouped");
 }
