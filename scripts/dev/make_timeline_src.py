@@ -24,8 +24,8 @@ src = sub1(src, "    __syncthreads();\n\n    // The scan advances in 64-row step
 src = sub1(src, "            set_tau(m);\n        }\n    };", "            set_tau(m);\n            TL(8);\n        }\n        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 101) && i < 96) g_tiles[(blockIdx.x ? 96 : 0) + i] = __builtin_amdgcn_s_memtime();\n    };")
 src = sub1(src, "    int t = 0;\n    while (t < T) {", "    int t = 0;\n    int n_rare = 0;\n    unsigned long long rare_cyc = 0;\n    while (t < T) {")
 src = sub1(src, "        if (!rare) break;\n", "        if (!rare) break;\n        ++n_rare;\n        const unsigned long long rc0 = __builtin_amdgcn_s_memtime();\n")
-src = sub1(src, "        if ((unsigned)t % (unsigned)H == H - 1) tile_end((int)((unsigned)t / (unsigned)H));\n        ++t;\n    }",
-    "        rare_cyc += __builtin_amdgcn_s_memtime() - rc0;\n        if ((unsigned)t % (unsigned)H == H - 1) tile_end((int)((unsigned)t / (unsigned)H));\n        ++t;\n    }")
+src = sub1(src, "        if (!defer && (unsigned)t % (unsigned)H == H - 1) tile_end((int)((unsigned)t / (unsigned)H));    // (rare implies t >= t_live)\n",
+    "        rare_cyc += __builtin_amdgcn_s_memtime() - rc0;   // (NB: hipcc may hoist the next step's MFMAs above this stamp when no tile ends here)\n        if (!defer && (unsigned)t % (unsigned)H == H - 1) tile_end((int)((unsigned)t / (unsigned)H));\n")
 src = sub1(src, "    if constexpr (THR) return;\n",
     "    TL(4);\n    if (threadIdx.x == 0) { g_tl[blockIdx.x * 16 + 6] = (unsigned long long)n_rare; g_tl[blockIdx.x * 16 + 10] = rare_cyc; }\n"
     "    if constexpr (THR) return;\n")
