@@ -11,17 +11,18 @@
 // The top-k rides on the THRESHOLD machinery of the rung (select.hip: THRESHOLD RUNG) instead of running lists:
 // the epilogue of a tile only compares its 128 scores per lane with the lane's fixed threshold and appends what
 // passes.  The threshold comes from LEVELS of evenly spread row samples:
-//   level 1   a sample of >= 2k rows, threshold -inf: every sampled row is kept; at least k of them have a scan
+//   level 1   a sample of up to `cap` rows (>= 2k), threshold -inf: every sampled row is kept; at least k of them have a scan
 //             score >= the k-th largest kept scan score s_k, hence an exact score >= s_k - (scan error bound): a
 //             valid LOWER BOUND of the true k-th score (k_bound_from_scan: a sort of scan scores, no row is read);
-//   level i   a sample `fmax` times larger scanned with threshold = (bound - error bound - one ulp): about
+//   level i   a sample r <= `fmax` times larger scanned with threshold = (bound - error bound - one ulp): about
 //             k * fmax rows pass per query -> a tighter bound the same way;
 //   last      every row.  What passes is everything that can still reach the k-th score already known -- near ties
 //             and duplicate rows included -- so the canonical float64 re-score of all of it (k_select_all) IS the
 //             exact answer (status 0); a query with more than 8192 such rows keeps status 1 and goes to the
-//             exhaustive kernels.  The last sample is 1/8 of the corpus: ~8 k rows per query reach the re-score.
-// Three to four passes, the last one dominant; no per-lane list, no shared threshold slots, no bootstrap.
+//             exhaustive kernels.  The last sample is 1/r of the corpus: ~r k rows per query reach the re-score.
+// Two to three passes, the last one dominant; no per-lane list, no shared threshold slots, no bootstrap.
 #include "scan.h"
+#include <cmath>
 #include "scan_dev.h"
 
 namespace sss {
@@ -252,21 +253,33 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     int rc = check_launch("k_query_f16 / k_iota");
     if (rc) return rc;
 
-    // ---- levels.  Tile counts grow geometrically: first a sample of >= 2k rows, kept whole (threshold -inf); then
-    // `fmax` times more rows per level -- about k * fmax rows pass a level's threshold, fmax = cap / (4 k) keeps a
-    // 2x margin below the capacity; the last sample is 1/8 of the corpus, so that only ~8 k rows per query pass
-    // the final threshold and have to be read back for the canonical re-score.  Intermediate levels read no row at
-    // all (k_bound_from_scan); the samples add 1/8 + 1/(8 fmax) + ... ~ 15 % to the matrix work.
+    // ---- levels (descending in level_tiles, run in reverse).  The first sample is as large as the capacity allows with
+    // the threshold at -inf (cap rows: every sampled row is kept) -- a 32-tile level costs the time of ONE tile, the chip
+    // being far from full, and its k-th best score is a much better bound than that of a 2k-row sample.  From there to
+    // the whole corpus the tile counts grow by equal factors r <= fmax = cap / (4 k): about k * r rows pass a level's
+    // threshold (2x margin below the capacity at r = fmax), the fewest levels that allows, and the factors balanced so
+    // that the last sample is as small as it can be (1M x 1600, K = 100: 32, 353, 3907 tiles -- the samples add ~10 % to
+    // the matrix work; it was 1, 24, 488, 3907).  Intermediate levels read no row at all (k_bound_from_scan).
     const int total_tiles = (int)((n + LT_ROWS - 1) / LT_ROWS);
     int fmax = LONG_CAP / (4 * k);
     if (fmax < 2) fmax = 2;
-    int first = (2 * k + LT_ROWS - 1) / LT_ROWS;
-    if (first < 1) first = 1;
+    int first = LONG_CAP / LT_ROWS;
+    if (first > total_tiles) first = total_tiles;
     int level_tiles[40];
     int levels = 0;
     level_tiles[levels++] = total_tiles;
-    for (int t = total_tiles / 8; t > first && levels < 38; t /= fmax) level_tiles[levels++] = t;
-    if (level_tiles[levels - 1] > first) level_tiles[levels++] = first;          // (descending; run in reverse)
+    if (first < total_tiles) {
+        const double span = (double)total_tiles / (double)first;
+        int steps = 1;
+        while (pow((double)fmax, (double)steps) < span && steps < 36) ++steps;      // growth steps from `first` to the corpus
+        const double r = pow(span, 1.0 / (double)steps);
+        for (int i = steps - 1; i >= 1; --i) {
+            int tl = (int)((double)first * pow(r, (double)i) + 0.5);
+            if (tl <= first) break;
+            if (tl < level_tiles[levels - 1]) level_tiles[levels++] = tl;
+        }
+        level_tiles[levels++] = first;
+    }
     ThrArgs t;
     t.Q = q; t.C = c_exact; t.qsel = qsel; t.nsel = (int)nq; t.d = d; t.dtype = exact_dtype; t.k = k; t.cap = LONG_CAP;
     t.scan_dtype = scan_dtype; t.corpus_shift = corpus_shift; t.corpus_resid = corpus_resid; t.corpus_max_norm = corpus_max_norm;

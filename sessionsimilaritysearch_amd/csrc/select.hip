@@ -27,6 +27,8 @@ constexpr int FS_CAP = 2048;       // candidates a wave stages in LDS (more -> u
 constexpr int FS_K2 = 32;          // candidates the wave-per-query kernel can re-score (its second chance widens K2 <= 16 up to this)
 constexpr int FS_COL = 16;         // candidate keys a lane keeps in registers (64 x 16 = 1024 candidates; more -> columns in LDS)
 constexpr int SEL_MAX_K2 = 512;
+constexpr int SA_ROWS = 128;       // k_select_all: survivors re-scored per group (one thread each)
+constexpr int SA_BYTES = 128;      //               bytes of every row staged through LDS per step
 constexpr int SORT_THREADS = 256;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -121,11 +123,20 @@ __device__ __forceinline__ double dot_chunk(double acc, const char* qrow, int v,
 // strictly sequential chain in k order.
 __device__ __forceinline__ double rescore_row(const char* qrow, const char* row, int nchunks, int dtype) {
     double acc = 0.0;
-    for (int v0 = 0; v0 < nchunks; v0 += 16) {
+    int v0 = 0;
+    // full batches: sixteen UNCONDITIONAL loads (a guarded load sits in a basic block of its own and hipcc then drains
+    // vmcnt before every one of them -- measured on 1600-wide rows: one load in flight, 1.4 us per 16-byte chunk)
+    for (; v0 + 16 <= nchunks; v0 += 16) {
         f32x4 c[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (v0 + i < nchunks) c[i] = *reinterpret_cast<const f32x4*>(row + (size_t)(v0 + i) * 16);
+        for (int i = 0; i < 16; ++i) c[i] = *reinterpret_cast<const f32x4*>(row + (size_t)(v0 + i) * 16);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = dot_chunk(acc, qrow, v0 + i, c[i], dtype);
+    }
+    if (v0 < nchunks) {                             // tail: the same loads clamped to the row's last chunk, their results unused
+        f32x4 c[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = *reinterpret_cast<const f32x4*>(row + (size_t)min(v0 + i, nchunks - 1) * 16);
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             if (v0 + i < nchunks) acc = dot_chunk(acc, qrow, v0 + i, c[i], dtype);
@@ -575,23 +586,45 @@ __device__ __forceinline__ void sort_desc(unsigned long long* keys, int M2, int 
     }
 }
 
-// The k-th largest score ordinal (high word of the keys) among keys[0 .. M), k <= M, by the whole workgroup: a
-// bit-by-bit descent -- "do at least k keys have an ordinal >= prefix | bit?" -- 32 counting rounds instead of a
-// sort of up to 8192 keys.  s_cnt: one shared word; every thread returns the same value.
-__device__ __forceinline__ unsigned kth_largest_ord(const unsigned long long* keys, int M, int k, int tid, unsigned* s_cnt) {
-    unsigned prefix = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const unsigned cand = prefix | (1u << bit);
-        if (tid == 0) *s_cnt = 0u;
+// The k-th largest score ordinal (high word of the keys) among keys[0 .. M), k <= M, by the whole workgroup of
+// SORT_THREADS = 256 threads: a radix descent, eight bits a pass -- a 256-bin histogram (LDS atomics) of the keys
+// that still match the prefix, then the bin holding the k-th from the top (one wave: four bins a lane, a suffix
+// sum by shuffles) -- four passes over the keys instead of a sort of up to 8192 of them (round 3; it was 32 one-bit
+// passes, 3 barriers each).  s_hist: 260 shared words; every thread returns the same value.
+__device__ __forceinline__ unsigned kth_largest_ord(const unsigned long long* keys, int M, int k, int tid, unsigned* s_hist) {
+    unsigned prefix = 0u, mask = 0u;
+    unsigned kk = (unsigned)k;                      // rank, from the top, inside the bucket that matches the prefix
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        s_hist[tid] = 0u;
         __syncthreads();
-        unsigned c = 0;
-        for (int x = tid; x < M; x += SORT_THREADS) c += (unsigned)(keys[x] >> 32) >= cand ? 1u : 0u;
+        for (int x = tid; x < M; x += SORT_THREADS) {
+            const unsigned o = (unsigned)(keys[x] >> 32);
+            if ((o & mask) == prefix) atomicAdd(&s_hist[(o >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const unsigned h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
+            const unsigned mine = h0 + h1 + h2 + h3;
+            unsigned suf = mine;                    // sum over this lane and every higher one
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += (unsigned)__shfl_xor((int)c, o);
-        if ((tid & 63) == 0 && c) atomicAdd(s_cnt, c);
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = (unsigned)__shfl_down((int)suf, o);
+                if (tid + o < 64) suf += v;
+            }
+            const unsigned above = suf - mine;
+            if (above < kk && suf >= kk) {          // the k-th from the top falls into this lane's four bins (exactly one lane)
+                unsigned cum = above;
+                int b = 3;
+                if (cum + h3 < kk) { cum += h3; b = 2; if (cum + h2 < kk) { cum += h2; b = 1; if (cum + h1 < kk) { cum += h1; b = 0; } } }
+                s_hist[256] = (unsigned)(4 * tid + b);
+                s_hist[257] = kk - cum;
+            }
+        }
         __syncthreads();
-        if (*s_cnt >= (unsigned)k) prefix = cand;
-        __syncthreads();
+        prefix |= s_hist[256] << shift;
+        mask |= 255u << shift;
+        kk = s_hist[257];
+        __syncthreads();                            // (the two words are rewritten in the next pass)
     }
     return prefix;
 }
@@ -601,13 +634,13 @@ __device__ __forceinline__ unsigned kth_largest_ord(const unsigned long long* ke
 // a valid LOWER BOUND of the query's true k-th score, written to column k-1 of its row of D_out (where the next
 // level's k_thr_prepare reads it).  Left unchanged when the kept rows overflowed the capacity or are fewer than k.
 __global__ __launch_bounds__(SORT_THREADS) void k_bound_from_scan(const ThrArgs A) {
-    __shared__ unsigned s_cnt;
+    __shared__ unsigned s_hist[260];
     const int i = blockIdx.x, tid = threadIdx.x;
     const int q = A.qsel[i];
     const int k = A.k;
     const unsigned M = A.cnt[i];
     if (M > (unsigned)A.cap || (int)M < k) return;
-    const unsigned sk = kth_largest_ord(A.cand + (size_t)i * A.cap, (int)M, k, tid, &s_cnt);
+    const unsigned sk = kth_largest_ord(A.cand + (size_t)i * A.cap, (int)M, k, tid, s_hist);
     if (tid < 64) {
         double B, unscale;
         query_bound(A, q, tid, B, unscale);
@@ -634,7 +667,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);             // [cap_pow2] kept rows (scan keys)
     unsigned long long* surv = keys + cap_pow2;                                          // [cap_pow2] survivors, then exact keys
     char* qrow = reinterpret_cast<char*>(surv + cap_pow2);
-    __shared__ unsigned s_cnt;
+    __shared__ unsigned s_hist[260];
     __shared__ float s_cut;
     __shared__ unsigned s_keep;
     const int i = blockIdx.x, tid = threadIdx.x;
@@ -652,7 +685,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
     if (tid == 0) { s_cut = -INFINITY; s_keep = 0u; }
     __syncthreads();
     if ((int)M > 2 * k + 64) {                                          // (worth a selection only when there is much to prune)
-        const unsigned sk_o = kth_largest_ord(keys, (int)M, k, tid, &s_cnt);
+        const unsigned sk_o = kth_largest_ord(keys, (int)M, k, tid, s_hist);
         if (tid < 64) {
             double B, unscale;
             query_bound(A, q, tid, B, unscale);
@@ -675,14 +708,48 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
     const int keep = (int)s_keep;                                       // >= k: the k-th largest itself passes the cut
     int K2 = 64;
     while (K2 < keep) K2 <<= 1;
-    for (int c = tid; c < K2; c += SORT_THREADS) {
-        unsigned long long key = 0ull;
-        if (c < keep) {
-            const int id = key_id(surv[c]);
-            const char* row = reinterpret_cast<const char*>(A.C) + (size_t)id * rb;
-            key = make_key((float)rescore_row(qrow, row, rb / 16, A.dtype), id);
+    // Canonical re-score of the survivors, SA_ROWS of them at a time, one thread per row for the strictly sequential
+    // float64 chain -- but the rows come in through LDS: the workgroup fetches 128 contiguous bytes of each of the
+    // group's rows per step (coalesced: eight lanes a row) and every thread then reads its own row's chunks from the
+    // staging tile.  (A thread walking its own 6400-byte row 16 bytes at a time -- round 3's first form -- turned
+    // every load into 64 separate line requests per wave: 0.53 ms of a 5.7 ms search at D = 1600, K = 100.)
+    char* stage = qrow + ((rb + 15) & ~15);                             // [SA_ROWS][SA_BYTES + 16]
+    const int nchunks = rb / 16;
+    for (int c0 = 0; c0 < K2; c0 += SA_ROWS) {
+        constexpr int PER = SA_ROWS * (SA_BYTES / 16) / SORT_THREADS;   // 16-byte pieces a thread fetches per step
+        f32x4 pre[PER];
+        auto fetch = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int idx = tid + SORT_THREADS * j, r = idx / (SA_BYTES / 16), ch = idx % (SA_BYTES / 16);
+                const int cs = min(c0 + r, keep - 1), vs = min(b + ch, nchunks - 1);      // (clamped: unused copies of valid bytes)
+                pre[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.C) + (size_t)key_id(surv[cs]) * rb + (size_t)vs * 16);
+            }
+        };
+        double acc = 0.0;
+        fetch(0);
+        for (int b = 0; b < nchunks; b += SA_BYTES / 16) {
+            __syncthreads();                                            // the previous step's tile has been consumed
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int idx = tid + SORT_THREADS * j, r = idx / (SA_BYTES / 16), ch = idx % (SA_BYTES / 16);
+                *reinterpret_cast<f32x4*>(stage + r * (SA_BYTES + 16) + ch * 16) = pre[j];
+            }
+            __syncthreads();
+            if (b + SA_BYTES / 16 < nchunks) fetch(b + SA_BYTES / 16);  // in flight under this step's chain
+            if (tid < SA_ROWS && c0 + tid < keep) {
+#pragma unroll
+                for (int i = 0; i < SA_BYTES / 16; ++i)
+                    if (b + i < nchunks)
+                        acc = dot_chunk(acc, qrow, b + i, *reinterpret_cast<const f32x4*>(stage + tid * (SA_BYTES + 16) + i * 16), A.dtype);
+            }
         }
-        keys[c] = key;                                                  // (the scan keys are no longer needed)
+        __syncthreads();                                                // (surv is read by every fetch; keys below aliases nothing)
+        if (tid < SA_ROWS && c0 + tid < K2) {
+            unsigned long long key = 0ull;
+            if (c0 + tid < keep) key = make_key((float)acc, key_id(surv[c0 + tid]));
+            keys[c0 + tid] = key;                                       // (the scan keys are no longer needed)
+        }
     }
     __syncthreads();
     sort_desc(keys, K2, tid);
@@ -768,16 +835,17 @@ int launch_select_all(const ThrArgs& a, hipStream_t st) {
     const int rb = a.d * elem_bytes(a.dtype);
     int cap_pow2 = 64;
     while (cap_pow2 < a.cap) cap_pow2 <<= 1;
-    const size_t lds = 2 * (size_t)cap_pow2 * 8 + rb;                 // kept keys + survivors + the query row
-    if (lds > 150 * 1024) { set_error("select_all: candidate capacity %d / row of %d bytes too large", a.cap, rb); return SSS_EINVAL; }
+    const size_t stage = (size_t)SA_ROWS * (SA_BYTES + 16);           // the re-score's staging tile
+    const size_t lds = 2 * (size_t)cap_pow2 * 8 + ((rb + 15) & ~15) + stage;   // kept keys + survivors + the query row + the tile
+    if (lds > 156 * 1024) { set_error("select_all: candidate capacity %d / row of %d bytes too large", a.cap, rb); return SSS_EINVAL; }
     static bool done[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_all), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_all), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         done[dev] = true;
     }
     const int small = cap_pow2 < 2048 ? cap_pow2 : 2048;
-    hipLaunchKernelGGL(k_select_all, dim3((unsigned)a.nsel), dim3(SORT_THREADS), 2 * (size_t)small * 8 + rb, st, a, small, 0);
+    hipLaunchKernelGGL(k_select_all, dim3((unsigned)a.nsel), dim3(SORT_THREADS), 2 * (size_t)small * 8 + ((rb + 15) & ~15) + stage, st, a, small, 0);
     if (small < cap_pow2) hipLaunchKernelGGL(k_select_all, dim3((unsigned)a.nsel), dim3(SORT_THREADS), lds, st, a, cap_pow2, 1);
     return check_launch("k_select_all");
 }
