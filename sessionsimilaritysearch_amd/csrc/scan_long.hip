@@ -36,6 +36,7 @@ struct LongArgs {
     const void* Qimg;               // [nq][d] 16-bit queries (f16: scaled image, bf16: the queries themselves)
     const void* C;                  // [n][d] 16-bit rows (f16 image / bf16 rows)
     int nq, n, d, G, S;
+    int dense;                      // sample level (many rows kept per lane and tile): aggregated appends
     int tile_count;                 // tiles this level scans: tile j of the level = corpus tile j * total_tiles / tile_count
     int total_tiles, tiles_per_split, cap;
     const float* thr;               // [nq] per-query threshold in the scan's domain
@@ -180,20 +181,69 @@ __global__ __launch_bounds__(512, 2) void k_scan_long(const LongArgs A) {
                 m1 = vmax3(m1, acc[b][1][jj], acc[b][1][jj + 1]);
             }
         }
-        if (__builtin_amdgcn_ballot_w64(m0 > thr0 || m1 > thr1) != 0) {
+        if (!A.dense) {
+            // the last level: a lane keeps a row of a tile now and then -- one atomic add per kept row
+            if (__builtin_amdgcn_ballot_w64(m0 > thr0 || m1 > thr1) != 0) {
+                const int row_base = tile * LT_ROWS + wr * 128 + 4 * h;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) {
+                        const int row = row_base + 32 * b + (jj & 3) + 8 * (jj >> 2);
+                        if (acc[b][0][jj] > thr0 && row < n) {
+                            const unsigned pos = atomicAdd(A.cnt + q0, 1u);
+                            if (pos < (unsigned)A.cap) A.cand[(size_t)q0 * A.cap + pos] = make_key(acc[b][0][jj], row);
+                        }
+                        if (acc[b][1][jj] > thr1 && row < n) {
+                            const unsigned pos = atomicAdd(A.cnt + q1, 1u);
+                            if (pos < (unsigned)A.cap) A.cand[(size_t)q1 * A.cap + pos] = make_key(acc[b][1][jj], row);
+                        }
+                    }
+                }
+            }
+        } else if (__builtin_amdgcn_ballot_w64(m0 > thr0 || m1 > thr1) != 0) {
+            // The sample levels keep many rows per lane and tile (the first one EVERY row: threshold -inf) -- one atomic
+            // add per lane and query for all of them (count, reserve, store); one per row made the first level cost
+            // four times its matrix work.  (On the last level the counting pass costs more than it saves: +9 %.)
             const int row_base = tile * LT_ROWS + wr * 128 + 4 * h;
+            unsigned n0 = 0u, n1 = 0u;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
 #pragma unroll
                 for (int jj = 0; jj < 16; ++jj) {
-                    const int row = row_base + 32 * b + (jj & 3) + 8 * (jj >> 2);
-                    if (acc[b][0][jj] > thr0 && row < n) {
-                        const unsigned pos = atomicAdd(A.cnt + q0, 1u);
-                        if (pos < (unsigned)A.cap) A.cand[(size_t)q0 * A.cap + pos] = make_key(acc[b][0][jj], row);
+                    const bool in = row_base + 32 * b + (jj & 3) + 8 * (jj >> 2) < n;
+                    n0 += (acc[b][0][jj] > thr0 && in) ? 1u : 0u;
+                    n1 += (acc[b][1][jj] > thr1 && in) ? 1u : 0u;
+                }
+            }
+            unsigned at0 = 0u, at1 = 0u;
+            if (n0) at0 = atomicAdd(A.cnt + q0, n0);
+            if (n1) at1 = atomicAdd(A.cnt + q1, n1);
+            unsigned long long* c0 = A.cand + (size_t)q0 * A.cap;
+            unsigned long long* c1 = A.cand + (size_t)q1 * A.cap;
+            if (__builtin_amdgcn_ballot_w64(n0 != 0u) != 0) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) {
+                        const int row = row_base + 32 * b + (jj & 3) + 8 * (jj >> 2);
+                        if (acc[b][0][jj] > thr0 && row < n) {
+                            if (at0 < (unsigned)A.cap) c0[at0] = make_key(acc[b][0][jj], row);
+                            ++at0;
+                        }
                     }
-                    if (acc[b][1][jj] > thr1 && row < n) {
-                        const unsigned pos = atomicAdd(A.cnt + q1, 1u);
-                        if (pos < (unsigned)A.cap) A.cand[(size_t)q1 * A.cap + pos] = make_key(acc[b][1][jj], row);
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(n1 != 0u) != 0) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) {
+                        const int row = row_base + 32 * b + (jj & 3) + 8 * (jj >> 2);
+                        if (acc[b][1][jj] > thr1 && row < n) {
+                            if (at1 < (unsigned)A.cap) c1[at1] = make_key(acc[b][1][jj], row);
+                            ++at1;
+                        }
                     }
                 }
             }
@@ -293,6 +343,7 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
         const int tiles = level_tiles[lv];
         const bool last = lv == 0;
         a.tile_count = tiles;
+        a.dense = last ? 0 : 1;
         int S = (256 / a.G) & ~7;
         if (S < 8) S = 8;
         while (S > 8 && S > tiles) S -= 8;

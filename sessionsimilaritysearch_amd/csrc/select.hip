@@ -715,6 +715,16 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
     // every load into 64 separate line requests per wave: 0.53 ms of a 5.7 ms search at D = 1600, K = 100.)
     char* stage = qrow + ((rb + 15) & ~15);                             // [SA_ROWS][SA_BYTES + 16]
     const int nchunks = rb / 16;
+    if (rb < 1024) {                                                    // short rows (a few lines each): a thread per row, all 256 busy
+        for (int c = tid; c < K2; c += SORT_THREADS) {
+            unsigned long long key = 0ull;
+            if (c < keep) {
+                const int id = key_id(surv[c]);
+                key = make_key((float)rescore_row(qrow, reinterpret_cast<const char*>(A.C) + (size_t)id * rb, nchunks, A.dtype), id);
+            }
+            keys[c] = key;
+        }
+    } else
     for (int c0 = 0; c0 < K2; c0 += SA_ROWS) {
         constexpr int PER = SA_ROWS * (SA_BYTES / 16) / SORT_THREADS;   // 16-byte pieces a thread fetches per step
         f32x4 pre[PER];
