@@ -154,7 +154,7 @@ def reference_shapes_leg(device, nq, sr, say):
               "ids_bit_exact": bool(np.array_equal(I, Ir)), "max_score_err": float(np.abs(D - Dr).max()), "queries_checked": 16,
               "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
                            "note": "whole search (sampled threshold levels + full scan + bounds + final re-score) / algorithmic FLOPs; "
-                                   "the scan itself moves ~28 GB through LDS-DMA per search, 0.8 of the chip's measured 6.4 TB/s ingest"}}
+                                   "the last level alone moves 25 GB through LDS-DMA in ~3.6 ms (7 TB/s, the path that bounds it: DESIGN.md 5.4)"}}
     del idx, c, out
     torch.cuda.empty_cache()
     cfg = EncoderConfig(d_in=768, h=800, n_layers=3, d_out=1600, n_items=100000, n_query=65)
