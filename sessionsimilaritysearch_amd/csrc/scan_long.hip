@@ -95,33 +95,40 @@ __global__ __launch_bounds__(512, 2) void k_scan_long(const LongArgs A) {
     // cover all 64 banks exactly once.  64 pieces per slab: wave w takes pieces w, w + 8, ... -- its first four are
     // corpus rows, its last four queries; the per-lane source addresses (without the slab offset) are kept in
     // registers: the queries' for the whole kernel, the rows' per tile.
+    // The DMA takes a uniform 64-bit base (the tile's / the query group's first row + the slab offset: scalar adds)
+    // and a per-lane 32-bit offset kept in registers: no vector address arithmetic per piece.
     const unsigned lds_base = (unsigned)(unsigned long)(lptr_c)smem;
-    const char* src_q[4];
-    const char* src_c[4];
+    unsigned off_q[4], off_c[4];
+    const char* q_base = Qb + (size_t)g * LT_Q * rb;
+    const char* c_base = Cb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int t = ((wave + 8 * i) << 3) + (lane >> 3);       // query row of the tile: pieces 32 + wave + 8 i
-        long row = (long)g * LT_Q + t;
-        if (row > (long)nq - 1) row = (long)nq - 1;             // short query batch: clamp
-        src_q[i] = Qb + (size_t)row * rb + ((lane & 7) ^ ((t >> 1) & 7)) * 16;
+        int tq = t;
+        if (g * LT_Q + tq > nq - 1) tq = nq - 1 - g * LT_Q;      // short query batch: clamp (the group holds >= 1 query)
+        off_q[i] = (unsigned)tq * (unsigned)rb + (unsigned)(((lane & 7) ^ ((t >> 1) & 7)) * 16);
     }
     auto set_tile = [&](int tile) __attribute__((always_inline)) {
+        c_base = Cb + (size_t)tile * LT_ROWS * rb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int t = ((wave + 8 * i) << 3) + (lane >> 3);   // corpus row of the tile: pieces wave + 8 i
-            long row = (long)tile * LT_ROWS + t;
-            if (row > (long)n - 1) row = (long)n - 1;           // ragged last tile: clamp
-            src_c[i] = Cb + (size_t)row * rb + ((lane & 7) ^ ((t >> 1) & 7)) * 16;
+            int tc = t;
+            if ((long)tile * LT_ROWS + tc > (long)n - 1) tc = (int)((long)n - 1 - (long)tile * LT_ROWS);   // ragged last tile: clamp
+            off_c[i] = (unsigned)tc * (unsigned)rb + (unsigned)(((lane & 7) ^ ((t >> 1) & 7)) * 16);
         }
     };
     auto stage = [&](int buf, int slab) __attribute__((always_inline)) {
         const size_t so = (size_t)slab * LT_BK;
+        const unsigned long cbv = (unsigned long)(c_base + so), qbv = (unsigned long)(q_base + so);
+        // (readfirstlane returns int: without the unsigned casts a low word with bit 31 set sign-extends into the high word)
+        const unsigned long cbs = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cbv >> 32)) << 32) | (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)cbv);
+        const unsigned long qbs = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(qbv >> 32)) << 32) | (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)qbv);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const char* src = (i < 4 ? src_c[i & 3] : src_q[i & 3]) + so;
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * LT_STAGE + ((i < 4 ? 0 : 32) + wave + 8 * (i & 3)) * 1024);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                         : : "v"(src), "s"(dst) : "memory");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                         : : "v"(i < 4 ? off_c[i & 3] : off_q[i & 3]), "s"(dst), "s"(i < 4 ? cbs : qbs) : "memory");
         }
     };
 
@@ -129,27 +136,41 @@ __global__ __launch_bounds__(512, 2) void k_scan_long(const LongArgs A) {
     f32x16 acc[4][2];
     const int keyq0 = ((wq * 64 + r) >> 1) & 7, keyq1 = ((wq * 64 + 32 + r) >> 1) & 7;
     const int total_steps = (j_hi - j_lo) * nslab;             // slab steps of this split
-    auto tile_of = [&](int j) __attribute__((always_inline)) { return (int)((long)j * A.total_tiles / A.tile_count); };
+    // tile j of the level = corpus tile floor(j * total_tiles / tile_count), advanced incrementally (one division here
+    // instead of a 64-bit scalar division sequence per tile)
+    const int t_quo = A.total_tiles / A.tile_count, t_rem = A.total_tiles % A.tile_count;
+    int tile = (int)((long)j_lo * A.total_tiles / A.tile_count);
+    int tile_frac = (int)((long)j_lo * A.total_tiles % A.tile_count);
+    auto next_tile = [&](int& tl, int& fr) __attribute__((always_inline)) {
+        tl += t_quo; fr += t_rem;
+        if (fr >= A.tile_count) { fr -= A.tile_count; ++tl; }
+    };
 
-    set_tile(tile_of(j_lo));
+    set_tile(tile);
     stage(0, 0);
     int step = 0;
     for (int j = j_lo; j < j_hi; ++j) {
-        const int tile = tile_of(j);
 #pragma unroll
         for (int b = 0; b < 4; ++b) { acc[b][0] = zero; acc[b][1] = zero; }
         for (int s = 0; s < nslab; ++s, ++step) {
             const int buf = step & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current slab have landed
             __syncthreads();                                    // ... everyone's have, and the other buffer is free
-            if (step + 1 < total_steps) {
-                if (s + 1 == nslab) { set_tile(tile_of(j + 1)); stage(buf ^ 1, 0); }
-                else stage(buf ^ 1, s + 1);
-            }
+            // The next slab's DMA (eight pieces, a few hundred cycles of issue): waves 0-3 issue it before their MFMAs,
+            // waves 4-7 -- their SIMD partners -- after the first half of theirs, so that one partner's issue burst
+            // runs beside the other's matrix work instead of both bursts leaving the pipe idle together.
+            auto issue_next = [&]() __attribute__((always_inline)) {
+                if (step + 1 < total_steps) {
+                    if (s + 1 == nslab) { int tl = tile, fr = tile_frac; next_tile(tl, fr); set_tile(tl); stage(buf ^ 1, 0); }
+                    else stage(buf ^ 1, s + 1);
+                }
+            };
+            if (wave < 4) issue_next();
             const char* rows = smem + buf * LT_STAGE;
             const char* qs = rows + LT_ROWS * LT_BK;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                if (u == 2 && wave >= 4) issue_next();
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(qs + (wq * 64 + r) * LT_BK + ((2 * u + h) ^ keyq0) * 16);
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(qs + (wq * 64 + 32 + r) * LT_BK + ((2 * u + h) ^ keyq1) * 16);
                 f32x4 a[4];
@@ -248,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void k_scan_long(const LongArgs A) {
                 }
             }
         }
+        next_tile(tile, tile_frac);
     }
 }
 
