@@ -171,6 +171,21 @@ def test_long_rows_take_the_k_tiled_scan(cuda, nq, n, d, k):
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
+@pytest.mark.parametrize("n,k", [(300, 1), (300, 100), (8192, 100), (8193, 100), (8448, 7), (70001, 1000), (70001, 1)])
+def test_long_rows_level_boundaries(cuda, n, k):
+    """The sample levels of the long-row search around their edges: a corpus that fits the first level whole (one level:
+    everything kept and re-scored), one row / one tile more than that (two levels of nearly equal size), a ragged last
+    tile, k = 1 and a k whose growth factor cap / (4 k) is the minimum 2; query batches that do not fill a query tile."""
+    rng = np.random.default_rng(n + k)
+    d, nq = 320, 37
+    q, c = _unit(rng, nq, d), _unit(rng, n, d)
+    idx = _index(c, cuda)
+    D, I = idx.search(q, k)
+    assert idx.last_scan == "long" and idx.last_rescan_queries == 0
+    Dr, Ir = sr.search_exact(q, c, k)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
 def test_long_rows_duplicates_ties_and_sorted_corpus(cuda):
     """Duplicate rows tie exactly (ascending id decides), a corpus sorted by score for one query, and a query with
     more tied rows than the scan keeps (-> status 1 -> exhaustive kernels): all exact."""
