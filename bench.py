@@ -33,6 +33,10 @@ ranks; `value` = queries / second of the whole job (every rank ends up with the 
 The corpus itself is built before the timed region by embedding synthetic sessions with the
 same encoder (index build; not timed, as in the reference where the index is built once).
 
+The default run (N = 1) also appends `reference_shapes`: the deployed model's OWN shapes, which are not the metric's
+configuration -- the long-row search at D = 1600, K = 100 over 1M random rows (checked against the oracle on 16 queries
+inside the run) and the encoder at d_in 768 / h 800 / 3 layers / D 1600 (`--no-reference-shapes` skips it).
+
 Extra JSON objects (see DESIGN.md "measurement"):
   roofline     -- dominant kernel k_scan<row bytes, tile rows, scan type>: algorithmic FLOPs per launch
                   / its mean duration, hipEvent-timed on its own stream inside the timed region;
