@@ -1,4 +1,4 @@
-"""Dev helper (not product): per-workgroup timeline of k_scan from a -DSSS_TIMELINE build of libsss
+"""Dev helper (not product): per-workgroup timeline of k_scan from the stamped build of libsss
 (scripts/dev/libsss_tl.so: see make_timeline_src.py).  Usage: timeline.py nq n d k"""
 import sys, os, ctypes, json
 import numpy as np
