@@ -187,6 +187,44 @@ __global__ __launch_bounds__(256) void k_segment_pool(const float* __restrict__ 
         const int p0 = pptr[g], p1 = pptr[g + 1], q0 = qptr[g], q1 = qptr[g + 1];
         const int cnt = (p1 - p0) + (q1 - q0);
         const float invc = 1.f / (float)(cnt > 0 ? cnt : 1);
+        // Wide rows with attention (the reference's D = 1600: 400 float4 columns over 64 lanes): ONE sweep over the
+        // graph's nodes -- a node's attention weight is computed once and applied to all of the lane's (up to eight)
+        // columns; the column-chunked sweeps below would recompute it, and re-read the node's A row, per chunk.
+        // Same additions in the same order per output element.
+        if (watt && nv > 2 * LPR && nv <= 8 * LPR) {
+            float4 acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < cnt; ++t) {
+                const long nrow = t < (p1 - p0) ? (long)(p0 + t) : n_clicks + (long)(q0 + t - (p1 - p0));
+                float part = 0.f;
+                for (int c = sub; c < nv; c += LPR) {
+                    const float4 a = *reinterpret_cast<const float4*>(A + nrow * ld_a + c * 4);
+                    const float4 b = *reinterpret_cast<const float4*>(bcoarse + g * ld_b + c * 4);
+                    const float4 w = *reinterpret_cast<const float4*>(watt + c * 4);
+                    part += w.x * sigmoidf_(a.x + b.x) + w.y * sigmoidf_(a.y + b.y) +
+                            w.z * sigmoidf_(a.z + b.z) + w.w * sigmoidf_(a.w + b.w);
+                }
+#pragma unroll
+                for (int o = LPR / 2; o > 0; o >>= 1) part += __shfl_xor(part, o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = sub + j * LPR;
+                    if (c < nv) {
+                        const float4 v = *reinterpret_cast<const float4*>(node + nrow * ld_node + c * 4);
+                        acc[j].x += part * v.x; acc[j].y += part * v.y; acc[j].z += part * v.z; acc[j].w += part * v.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = sub + j * LPR;
+                if (c < nv)
+                    *reinterpret_cast<float4*>(out + g * ld_out + c * 4) =
+                        make_float4(acc[j].x * invc, acc[j].y * invc, acc[j].z * invc, acc[j].w * invc);
+            }
+            continue;
+        }
         // two float4 columns per lane per sweep (named accumulators, never runtime-indexed);
         // rows wider than 8 * LPR floats take several sweeps over the graph's nodes
         for (int cb = 0; cb < nv; cb += 2 * LPR) {
