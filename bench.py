@@ -173,7 +173,7 @@ def reference_shapes_leg(device, nq, sr, say):
     e1.record(); torch.cuda.synchronize()
     ems = e0.elapsed_time(e1) / iters
     encoder = {"d_in": 768, "h": 800, "layers": 3, "d_out": 1600, "sessions": nq, "ms_per_forward": round(ems, 4),
-               "value": round(nq / (ems * 1e-3), 1), "unit": "sessions/s", "path": "fused" if enc.fused_ok() else "per-op kernels (GEMM-bound: ~83 % of the time in k_linear_*)"}
+               "value": round(nq / (ems * 1e-3), 1), "unit": "sessions/s", "path": "fused" if enc.fused_ok() else "per-op kernels (GEMM-bound: ~86 % of the time in k_linear_grouped at ~0.73 of the f32 MFMA peak)"}
     return {"note": "the deployed model's own shapes, same run; not the metric's configuration", "search": search, "encoder": encoder,
             "ms_per_step": round(ms + ems, 4), "value": round(nq / ((ms + ems) * 1e-3), 1), "unit": "queries/s"}
 
