@@ -91,7 +91,7 @@ static int ip_topk_impl(const void* q, long nq, const void* c_scan, int scan_dty
     ScanArgs a;
     a.Q = q; a.C = c_scan; a.nq = (int)nq; a.n = (int)n;
     a.tiles_per_split = p.tiles_per_split; a.total_tiles = p.total_tiles;
-    a.S = p.S; a.G = p.G; a.J = p.J; a.Ju = p.Ju; a.cert = p.cert; a.boot = p.boot; a.cap = p.cap;
+    a.S = p.S; a.G = p.G; a.J = p.J; a.Ju = p.Ju; a.cert = p.cert; a.boot = p.boot; a.append = p.append; a.cap = p.cap;
     unsigned* sw = reinterpret_cast<unsigned*>(state);
     a.slots = sw;
     a.cnt = sw + state_off_cnt(nq);
@@ -155,7 +155,7 @@ int ip_topk_threshold(const void* q, const int* qsel, long nsel, const void* c_e
     ScanArgs a = {};
     a.Q = q; a.C = c_scan; a.nq = (int)nsel; a.n = (int)n;
     a.tiles_per_split = p.tiles_per_split; a.total_tiles = p.total_tiles;
-    a.S = p.S; a.G = p.G; a.J = 0; a.Ju = 0; a.cert = 1; a.boot = 0; a.cap = p.cap;
+    a.S = p.S; a.G = p.G; a.J = 0; a.Ju = 0; a.cert = 1; a.boot = 0; a.append = 0; a.cap = p.cap;
     a.slots = nullptr; a.cnt = t.cnt; a.maxlast = nullptr;
     a.cand = const_cast<unsigned long long*>(t.cand);
     a.qsel = qsel; a.thr = t.thr;

@@ -50,7 +50,7 @@ static inline size_t state_words(long nq) { return state_off_maxlast(nq) + 2 * (
 
 // Per-search plan (host).  Workspace: cand u64 [nq][cap] compacted candidate keys, cap = L * KP.
 struct ScanPlan {
-    int G, S, L, K2, J, Ju, cert, boot, tile_rows;      // J slots per query, Ju <= J distinct classes (J == 16: the rest mirror them)
+    int G, S, L, K2, J, Ju, cert, boot, append, tile_rows;      // J slots per query, Ju <= J distinct classes (J == 16: the rest mirror them)
     int total_tiles, tiles_per_split, cap;
     size_t total_bytes;
 };
@@ -60,7 +60,7 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype);
 struct ScanArgs {
     const void* Q;
     const void* C;
-    int nq, n, tiles_per_split, total_tiles, S, G, J, Ju, cert, boot, cap;
+    int nq, n, tiles_per_split, total_tiles, S, G, J, Ju, cert, boot, append, cap;
     unsigned* slots;                // the three arrays live in the caller's state buffer
     unsigned* cnt;
     unsigned long long* maxlast;

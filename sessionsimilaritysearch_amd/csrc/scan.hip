@@ -40,6 +40,7 @@
 //     (one atomic add per lane) for k_select_* (select.hip).
 #include "scan.h"
 #include "scan_dev.h"
+#include <cstdlib>
 
 #ifndef SSS_STAGGER
 #define SSS_STAGGER 1
@@ -53,15 +54,15 @@ namespace sss {
 // ip_topk.hip: ip_topk_threshold): the queries are the compact list A.qsel, every lane compares against
 // its query's FIXED threshold A.thr[] (scan domain) instead of a running list, and every row above it is
 // appended to the query's candidate array -- no lists, no shared threshold, no bootstrap.
-template <int RB, int TR, int DT, int NW, bool THR = false>
-__global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
+template <int RB, int TR, int DT, int NW, bool THR = false, bool AP = false>
+__global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(const ScanArgs A) {
     constexpr int H = TR / 64;                        // 64-row sub-steps per tile
     constexpr int CH = RB / 16;                       // 16-byte chunks per row
     constexpr int NU = RB / 32;                       // k-groups per row (one b128 fragment each)
     constexpr int TILE_BYTES = TR * RB;
     constexpr int LOADS_PER_WAVE = TR * CH / 64 / NW; // LDS-DMA wave-instructions per wave per tile
     constexpr int WGQ = NW * 32;                      // queries per workgroup
-    constexpr bool PRECOMP = RB <= 512;               // keep the DMA lane offsets in VGPRs (register budget)
+    constexpr bool PRECOMP = RB <= 512 && !AP;        // keep the DMA lane offsets in VGPRs (register budget; not at 128 VGPRs)
     constexpr int TAU_LDS = 2 * TILE_BYTES;           // [8 waves][32 queries][16 slots] u32 behind the two tile buffers
     static_assert(CH <= 64, "row longer than one LDS-DMA instruction");
     static_assert(LOADS_PER_WAVE >= 1, "a tile is at least one DMA piece per wave");
@@ -98,6 +99,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     for (int i = 0; i < KP; ++i) { ls[i] = -INFINITY; li[i] = -1; }
     float pend_s = -INFINITY;   // one parked candidate per lane (see the epilogue)
     int pend_i = -1;
+    // AP (append form: K2 <= 16 with the bootstrap, 256-byte rows): the shared threshold alone decides what is kept,
+    // so a lane needs no sorted list -- passing rows go into a small unsorted register buffer that is handed to the
+    // query's candidate array when it is full and at the end (ls / li / pend_* are dead in this form).  Half the
+    // registers: TWO workgroups per CU, four waves per SIMD.
+    constexpr int E = 4;
+    float es[E];
+    int ei[E];
+    int ecnt = 0;
+#pragma unroll
+    for (int i = 0; i < E; ++i) { es[i] = -INFINITY; ei[i] = -1; }
     float tau = -INFINITY, thr = -INFINITY;
     if constexpr (THR) thr = q_glob < nq ? A.thr[q_glob] : INFINITY;    // padding lanes never emit
     float rmax = -INFINITY;     // best score this lane has seen (published when cert == 1)
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
     };
     auto set_tau = [&](unsigned m) {
         if (m > ORD_NEG_INF) tau = fmaxf(tau, ord2f(m - 1));     // the float just below the min slot
-        thr = fmaxf(ls[KP - 1], tau);
+        thr = AP ? tau : fmaxf(ls[KP - 1], tau);
     };
     auto publish = [&]() {
         float val = rmax;
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         // A fragments PF k-groups ahead of their MFMAs: the f32 MFMA spends 512 cycles on a group, one
         // group ahead covers the LDS latency; the 16-bit MFMAs spend 64-128, so their reads run further
         // ahead (all of a 256-byte row's fragments at once -- the registers are there).
-        constexpr int PF = DT == DT_F32 ? 1 : (RB == 256 ? NU : RB == 512 ? 4 : 2);
+        constexpr int PF = DT == DT_F32 ? 1 : AP ? 1 : (RB == 256 ? NU : RB == 512 ? 4 : 2);
         f32x4 as0[NU], as1[NU];
 #pragma unroll
         for (int u = 0; u < PF && u < NU; ++u) { const f32x4* p = lda(u); as0[u] = p[0]; as1[u] = p[32 * CH]; }
@@ -328,6 +339,48 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         };
         walk(q0, 0); walk(q1, 4); walk(q2, 8); walk(q3, 12);     // ascending row order per lane
     };
+    // AP: lanes flagged `need` hand their buffered rows to the query's candidate array (one atomic add per lane; what
+    // does not fit the capacity is remembered as the largest lost key, exactly like the tail of a full list).
+    auto flush = [&](bool need) {
+        if (need && q_glob < nq) {
+            const unsigned at = atomicAdd(A.cnt + q_glob, (unsigned)ecnt);
+            unsigned long long* dst = A.cand + (size_t)q_glob * A.cap;
+            unsigned long long lost = 0ull;
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                if (i < ecnt) {
+                    const unsigned long long key = make_key(es[i], ei[i]);
+                    if (at + (unsigned)i < (unsigned)A.cap) dst[at + i] = key;
+                    else lost = lost > key ? lost : key;
+                }
+            }
+            if (lost != 0ull) atomicMax(A.maxlast + q_glob, lost);
+        }
+        ecnt = need ? 0 : ecnt;
+    };
+    auto append_block = [&](const f32x16& a, int base) {
+        float q0, q1, q2, q3;
+        const float m = block_max(a, q0, q1, q2, q3);
+        if (__builtin_amdgcn_ballot_w64(m > thr) == 0) return;
+        auto walk = [&](float qm, int j0) {
+            if (__builtin_amdgcn_ballot_w64(qm > thr) == 0) return;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = j0 + jj;
+                const bool pass = a[j] > thr;
+                if (__builtin_amdgcn_ballot_w64(pass) != 0) {
+                    const bool full = pass && ecnt == E;
+                    if (__builtin_amdgcn_ballot_w64(full) != 0) flush(full);
+#pragma unroll
+                    for (int i = E - 1; i > 0; --i) { es[i] = pass ? es[i - 1] : es[i]; ei[i] = pass ? ei[i - 1] : ei[i]; }
+                    es[0] = pass ? a[j] : es[0];
+                    ei[0] = pass ? base + (j & 3) + 8 * (j >> 2) : ei[0];
+                    ecnt += pass ? 1 : 0;
+                }
+            }
+        };
+        walk(q0, 0); walk(q1, 4); walk(q2, 8); walk(q3, 12);
+    };
     // THR: every score above the lane's fixed threshold goes straight to the query's candidate array
     // (rare by construction: the threshold sits an error bound below the k-th best score already known).
     auto emit_block = [&](const f32x16& a, int base) {
@@ -393,7 +446,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
             // within a microsecond of each other; if not, the bound expires and the scan simply
             // runs with a weaker (or no) threshold -- correctness never depends on it.
             unsigned m = 0;
-            for (int it = 0; it < 24; ++it) {
+            // (the append form has nothing but the threshold to hold rows back: it waits much longer before it gives up)
+            for (int it = 0; it < (AP ? 1024 : 24); ++it) {
                 m = tau_ord();
                 if (__builtin_amdgcn_ballot_w64(m == 0) == 0) break;
                 __builtin_amdgcn_s_sleep(16);
@@ -453,6 +507,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         if constexpr (THR) {
             emit_block(acc0, (int)row0_of_step + 4 * h);
             emit_block(acc1, (int)row0_of_step + 32 + 4 * h);
+        } else if constexpr (AP) {
+            append_block(acc0, (int)row0_of_step + 4 * h);
+            append_block(acc1, (int)row0_of_step + 32 + 4 * h);
         } else {
             insert_block(acc0, (int)row0_of_step + 4 * h);
             insert_block(acc1, (int)row0_of_step + 32 + 4 * h);
@@ -461,9 +518,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_scan(const ScanArgs A) {
         ++t;
     }
     if constexpr (THR) return;
+    if constexpr (AP) flush(ecnt > 0);
     list_insert<KP>(ls, li, pend_s, pend_i);   // no-op for lanes with an empty slot (-inf)
-    // ---- append the real entries to the query's compact candidate array
-    if (q_glob < nq) {
+    // ---- append the real entries to the query's compact candidate array (none in the append form: li stayed -1)
+    if (!AP && q_glob < nq) {
         int nreal = 0;
 #pragma unroll
         for (int i = 0; i < KP; ++i) nreal += li[i] >= 0 ? 1 : 0;
@@ -497,7 +555,20 @@ constexpr int TR256_MIN_TILES = 24;     // splits at least this many 256-row til
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+static ScanPlan make_plan_for(long nq, long n, int d, int k, int dtype, bool want_append);
 ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
+    // The append form (k <= 16 on 256-byte rows of a 16-bit scan: no lane lists, half the registers) runs TWO
+    // workgroups per CU on twice the splits; it needs the bootstrap (a shared threshold from the first live row on) and
+    // splits long enough to be worth it -- otherwise the plan with lane lists.
+    static const int ap_off = getenv("SSS_SCAN_AP_OFF") ? 1 : 0;       // (dev A/B switch)
+    const int rb = d * elem_bytes(dtype);
+    if (!ap_off && rb == 256 && dtype != DT_F32 && k <= KP) {
+        const ScanPlan a = make_plan_for(nq, n, d, k, dtype, true);
+        if (a.append) return a;
+    }
+    return make_plan_for(nq, n, d, k, dtype, false);
+}
+static ScanPlan make_plan_for(long nq, long n, int d, int k, int dtype, bool want_append) {
     ScanPlan p;
     const int rb = d * elem_bytes(dtype);
     const int wgq = rb == 1024 ? 128 : WG_QUERIES;      // queries per workgroup (k_scan's NW * 32)
@@ -510,6 +581,13 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     // 256-byte rows: 256-row tiles (one barrier and one threshold refresh per 256 rows, the next tile's
     // DMA a whole tile ahead) once a split is long enough to amortise the twice-scanned bootstrap tile
     if (rb == 256 && dtype != DT_F32 && n / ((long)S * 256) >= TR256_MIN_TILES) tr = 256;
+    if (want_append) {                                    // 2 S splits of 128-row tiles, S * G <= 256
+        tr = 128;
+        S = pick_splits(n, p.G, tr);
+        if ((long)S * p.G > 256 || (long)2 * S * tr * 8 > n) want_append = false;      // (>= 8 tiles a split after doubling)
+        else S *= 2;
+        if (!want_append) { ScanPlan none; none.append = 0; return none; }
+    }
     p.tile_rows = tr;
     p.S = S;
     p.L = 2 * S;
@@ -537,6 +615,9 @@ ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     p.Ju = (p.cert == 1 && p.K2 < p.J) ? p.K2 : p.J;
     if (p.J * p.cert < p.K2 || 2 * active_splits < p.Ju) { p.J = 0; p.Ju = 0; }      // tiny corpus: no threshold
     p.boot = (p.J > 0 && p.cert == 1) ? 1 : 0;
+    p.append = (want_append && p.boot) ? 1 : 0;
+    if (want_append && !p.append) return p;               // (the caller falls back to the list plan)
+    if (p.append) p.cap = 2048;                            // candidates per query the select kernels stage (FS_CAP)
     p.total_bytes = align256((size_t)nq * p.cap * 8);
     return p;
 }
@@ -558,17 +639,17 @@ ScanPlan make_thr_plan(long nsel, long n, int d, int scan_dtype, int cap) {
     return p;
 }
 
-template <int RB, int TR, int DT, int NW, bool THR>
+template <int RB, int TR, int DT, int NW, bool THR, bool AP = false>
 static int launch_form(const ScanArgs& a, hipStream_t st) {
     const size_t lds = 2 * (size_t)TR * RB + NW * 2048;      // two tile buffers + the threshold-slot staging
     static bool attr_done[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<RB, TR, DT, NW, THR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan<RB, TR, DT, NW, THR, AP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL((k_scan<RB, TR, DT, NW, THR>), dim3(a.S * a.G), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((k_scan<RB, TR, DT, NW, THR, AP>), dim3(a.S * a.G), dim3(NW * 64), lds, st, a);
     return check_launch("k_scan");
 }
 template <int RB, int TR, int DT, int NW = 8>
@@ -577,6 +658,11 @@ static int launch_one(const ScanArgs& a, hipStream_t st) {
     if (a.thr != nullptr) {
         if constexpr (TR == (RB <= 512 ? 128 : 64)) return launch_form<RB, TR, DT, NW, true>(a, st);
         set_error("scan: threshold form not built for %d-row tiles of %d-byte rows", TR, RB);
+        return SSS_EINVAL;
+    }
+    if (a.append) {
+        if constexpr (RB == 256 && TR == 128 && DT != DT_F32) return launch_form<RB, TR, DT, NW, false, true>(a, st);
+        set_error("scan: append form not built for this shape");
         return SSS_EINVAL;
     }
     return launch_form<RB, TR, DT, NW, false>(a, st);

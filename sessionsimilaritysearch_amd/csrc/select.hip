@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     const int K2 = A.K2, k = A.k;
     float* Dq = A.D_out + (size_t)q * k;
     long* Iq = A.I_out + (size_t)q * k;
-    const int M = (int)A.cnt[q];
+    const int M = (int)min(A.cnt[q], (unsigned)A.cap);            // (the append form of k_scan counts what it could not store, too)
     if (M > FS_CAP) {                                             // adversarial input: let the exhaustive path decide
         for (int j = lane; j < k; j += 64) { Dq[j] = -3.4028234663852886e38f; Iq[j] = -1; }   // (no k-th score known)
         if (lane == 0) { A.status[q] = 1; if (A.unproven_count) atomicAdd(A.unproven_count, 1); }
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
     const int K2 = A.K2, k = A.k;
     float* Dq = A.D_out + (size_t)q * k;
     long* Iq = A.I_out + (size_t)q * k;
-    const int M = (int)A.cnt[q];
+    const int M = (int)min(A.cnt[q], (unsigned)A.cap);            // (the append form of k_scan counts what it could not store, too)
     int M2 = 64;
     while (M2 < M || M2 < K2) M2 <<= 1;                            // <= cap_pow2 by construction
     const unsigned long long* ck = A.cand + (size_t)q * A.cap;
