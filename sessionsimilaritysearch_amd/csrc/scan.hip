@@ -7,7 +7,7 @@
 // stored rows and proves, per query, that nothing outside them could matter (error bound per scan
 // type: select.hip err_bound).
 //
-// k_scan<RB, TR, DT, NW>  -- the dominant kernel (DESIGN.md "scoring kernel"); RB = bytes per scanned
+// k_scan<RB, TR, DT, NW, THR, AP>  -- the dominant kernel (DESIGN.md "scoring kernel"); RB = bytes per scanned
 // corpus row (256 / 512 / 1024), TR = rows per LDS tile (64 / 128 / 256), DT = element type (scan.h),
 // NW = waves per workgroup:
 //   * one workgroup = 8 waves (2 per SIMD) = 256 queries x one contiguous corpus split (1024-byte
@@ -37,7 +37,11 @@
 //     ever hold scores of real rows and only grow, so a stale read merely admits extra candidates:
 //     speed, never correctness;
 //   * at the end each lane appends its real entries to the query's compact candidate array
-//     (one atomic add per lane) for k_select_* (select.hip).
+//     (one atomic add per lane) for k_select_* (select.hip);
+//   * AP = true, the APPEND form (k <= 16 on 256-byte rows of a 16-bit scan, with the bootstrap): the shared
+//     threshold alone decides what is kept, so a lane needs no sorted list -- a 4-entry unsorted register
+//     buffer, flushed to the candidate array when full and at the end.  128 VGPRs instead of 223: TWO
+//     workgroups per CU (four waves per SIMD) on twice the splits.
 #include "scan.h"
 #include "scan_dev.h"
 #include <cstdlib>
