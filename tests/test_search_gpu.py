@@ -543,6 +543,48 @@ def test_f16_scan_near_ties_inside_its_error_bound(cuda):
 # ----------------------------------------------------------------------------------------------
 # bf16 index (BASELINE config C5): corpus and queries stored as bfloat16, scored on the bf16 MFMA
 # with float32 accumulation; the contract is the canonical float64 score of the ROUNDED vectors.
+@pytest.mark.parametrize("k", [1, 10, 16])
+def test_append_form_of_the_16bit_scan(cuda, k):
+    """k <= 16 on 256-byte rows of a 16-bit scan with splits of >= 8 tiles runs the APPEND form of k_scan (no lane lists,
+    two workgroups per CU: scan.hip header): random rows, a ragged query batch, and both 16-bit flavours (f16 image of an
+    f32 index, bf16 index)."""
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(700 + k)
+    n, nq, d = 300_001, 601, 128
+    q, c = _unit(rng, nq, d), _unit(rng, n, d)
+    idx = _index(c, cuda, scan="f16")
+    D, I = idx.search(q, k)
+    Dr, Ir = sr.search_exact(q, c, k)
+    assert idx.last_scan == "f16" and idx.last_rescan_queries <= 2
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    qb, cb = _bf16_round(q), _bf16_round(c)
+    idx = FlatIndex(d, "ip", cuda, dtype="bf16")
+    idx.add(cb)
+    D, I = idx.search(qb, k)
+    Dr, Ir = sr.search_exact(qb, cb, k)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
+def test_append_form_flushes_and_overflows(cuda):
+    """Rows that pass in bulk: 3000 copies of one direction score (nearly) the same for the queries near it -- a lane's
+    4-entry buffer flushes over and over, the 2048-entry candidate array of those queries overflows (the largest lost key
+    is recorded, the proof fails, the threshold rung / exhaustive kernels decide); everything stays exact, ascending id
+    inside the ties."""
+    rng = np.random.default_rng(77)
+    n, d, k = 300_000, 128, 10
+    c = _unit(rng, n, d)
+    hot = _unit(rng, 1, d)
+    where = rng.choice(n, 3000, replace=False)
+    c[where] = hot
+    q = _unit(rng, 40, d)
+    q[:8] = sr.normalize(hot + 0.05 * rng.standard_normal((8, d)).astype(np.float32)).astype(np.float32)
+    idx = _index(c, cuda, scan="f16")
+    D, I = idx.search(q, k)
+    Dr, Ir = sr.search_exact(q, c, k)
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    assert np.array_equal(I[0], np.sort(where)[:k])
+
+
 def _bf16_round(x):
     return torch.from_numpy(x).to(torch.bfloat16).float().numpy()
 
