@@ -14,10 +14,10 @@ def sub1(s, old, new):
     assert s.count(old) == 1, (s.count(old), old)
     return s.replace(old, new)
 
-src = sub1(src, "template <int RB, int TR, int DT, int NW, bool THR = false>\n",
+src = sub1(src, "template <int RB, int TR, int DT, int NW, bool THR = false, bool AP = false>\n",
     "__device__ unsigned long long g_tl[1024 * 16];\n__device__ unsigned long long g_tiles[192];\n"
     "#define TL(slot) do { if (threadIdx.x == 0) g_tl[blockIdx.x * 16 + (slot)] = ((slot) == 0 || (slot) == 7 || (slot) == 9) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)\n"
-    "template <int RB, int TR, int DT, int NW, bool THR = false>\n")
+    "template <int RB, int TR, int DT, int NW, bool THR = false, bool AP = false>\n")
 src = sub1(src, "    constexpr int H = TR / 64;", "    TL(0); TL(1);\n    constexpr int H = TR / 64;")
 src = sub1(src, "    if (ntiles > 0) stage(0, tile_lo);\n", "    TL(2);\n    if (ntiles > 0) stage(0, tile_lo);\n")
 src = sub1(src, "    __syncthreads();\n\n    // The scan advances in 64-row steps", "    __syncthreads();\n    TL(3); TL(9);\n\n    // The scan advances in 64-row steps")

@@ -21,7 +21,7 @@ for _ in range(20):
     idx.search_fused(q, k, out)
 torch.cuda.synchronize()
 L = _lib.lib()
-nwg = 256
+nwg = 512
 W = 16
 buf = (ctypes.c_ulonglong * (nwg * W))()
 fn = L.sss_debug_timeline
