@@ -560,13 +560,33 @@ constexpr int TR256_MIN_TILES = 24;     // splits at least this many 256-row til
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static ScanPlan make_plan_for(long nq, long n, int d, int k, int dtype, bool want_append);
+
+// The append form's bootstrap hand-shake needs all 2 x 256 workgroups resident at once: ask the runtime, once per
+// device, whether two of its workgroups (80 KB of LDS, 128 VGPRs each) fit a CU and the chip has the CUs -- otherwise
+// (another LDS carve-out, a smaller part) the plan keeps the list form.
+static bool append_form_fits() {
+    static int cached[MAX_DEVICES] = {};                 // 0 unknown, 1 yes, 2 no
+    const int dev = current_device();
+    if (cached[dev] == 0) {
+        constexpr int lds = 2 * 128 * 256 + 8 * 2048;
+        const void* fn = reinterpret_cast<const void*>(&k_scan<256, 128, DT_F16, 8, false, true>);
+        int blocks = 0, cus = 0;
+        bool ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess &&
+                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 512, lds) == hipSuccess &&
+                  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess;
+        (void)hipGetLastError();
+        cached[dev] = (ok && blocks >= 2 && cus >= 256) ? 1 : 2;
+    }
+    return cached[dev] == 1;
+}
+
 ScanPlan make_plan(long nq, long n, int d, int k, int dtype) {
     // The append form (k <= 16 on 256-byte rows of a 16-bit scan: no lane lists, half the registers) runs TWO
     // workgroups per CU on twice the splits; it needs the bootstrap (a shared threshold from the first live row on) and
     // splits long enough to be worth it -- otherwise the plan with lane lists.
     static const int ap_off = getenv("SSS_SCAN_AP_OFF") ? 1 : 0;       // (dev A/B switch)
     const int rb = d * elem_bytes(dtype);
-    if (!ap_off && rb == 256 && dtype != DT_F32 && k <= KP) {
+    if (!ap_off && rb == 256 && dtype != DT_F32 && k <= KP && append_form_fits()) {
         const ScanPlan a = make_plan_for(nq, n, d, k, dtype, true);
         if (a.append) return a;
     }
