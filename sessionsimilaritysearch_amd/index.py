@@ -22,13 +22,15 @@ from . import _lib
 FUSED_DIMS = {"f32": (64, 128, 256), "bf16": (128, 256, 512)}   # row bytes 256 / 512 / 1024
 F16_SCAN_DIMS = (128, 256, 512)                                  # scaled-f16 image: 2 bytes per element
 # scan="auto": the fastest scan whose error bound is still small against the spacing of the scores
-# around rank k (the spacing shrinks as k grows): one-pass f16 up to k = 16, bf16 split up to
-# k = 128, the f32 MFMA beyond.  A search whose fallback share exceeds AUTO_ESCALATE moves that k
-# class one scan up for the following searches (near-duplicate-heavy corpora): an unproven query
-# costs an O(n d) float64 pass, ~25 us per query per million rows, so half a percent of a batch
-# already outweighs what the faster scan saves.
-AUTO_F16_MAX_K = 16
-AUTO_SPLIT_MAX_K = 128
+# around rank k (the spacing shrinks as k grows): one-pass f16 up to k = 128, bf16 split up to k = 500
+# (every k the fused path serves); the f32 MFMA scan is reached by escalation only.  Measured on random unit
+# rows, d = 128, 1024 queries (round 3): f16 leaves 0 of 6144 queries unproven at k <= 64 on 10M rows, 8 at k = 128,
+# 60 at k = 200 (the k classes are cut there); split leaves 0-1 up to k = 500, at 0.4x the f32 scan's time.  A
+# search whose fallback share exceeds AUTO_ESCALATE moves that k class one scan up for the following searches
+# (near-duplicate-heavy or unusually dense corpora); an unproven query costs a share of one more scan of the
+# corpus for the unproven ones only (the threshold rung), so a few per batch are cheaper than the slower scan.
+AUTO_F16_MAX_K = 128
+AUTO_SPLIT_MAX_K = 500
 AUTO_ESCALATE = 0.005
 AUTO_DECAY_SEARCHES = 64        # clean searches at an escalated level before the class steps back down one scan
 _LADDER = ("f16", "split", "f32")
@@ -235,13 +237,29 @@ class FlatIndex:
         """scan="auto": move this k class one scan up when too many queries of a search were left
         unproven by it -- only to a scan this d can run -- and back down one scan after
         AUTO_DECAY_SEARCHES consecutive clean searches (one near-duplicate-heavy batch does not demote
-        the index for good)."""
+        the index for good); an escalation that proves no more queries than the faster scan did is undone."""
         if self.scan != "auto" or self.last_scan not in _LADDER:
             return
         kc = self._k_class(k)
+        share = bad / max(nq, 1)
+        # The first search after an escalation tells whether it helped: exact ties (duplicate rows at the k-th place)
+        # stay unproven under EVERY scan -- the threshold rung resolves them, at a cost that hardly depends on how
+        # many there are -- so a slower scan that still leaves more than AUTO_ESCALATE of the batch unproven only
+        # costs time.  Such a step is taken back and the class pinned for AUTO_DECAY_SEARCHES searches.
+        probe = self._auto_clean.pop(("probe", kc), None)
+        if probe is not None and nq >= 32 and bad >= 4 and share > AUTO_ESCALATE:
+            self._auto_level[kc] = probe[0]
+            self._auto_clean[("pin", kc)] = AUTO_DECAY_SEARCHES
+            self._auto_clean[kc] = 0
+            return
+        pin = self._auto_clean.get(("pin", kc), 0)
+        if pin > 0:
+            self._auto_clean[("pin", kc)] = pin - 1
+            return
         if nq >= 32 and bad >= 4 and bad > AUTO_ESCALATE * nq:
             up = self.next_scan(self.last_scan)
             if up:
+                self._auto_clean[("probe", kc)] = (_LADDER.index(self.last_scan), share)
                 self._auto_level[kc] = _LADDER.index(up)
             self._auto_clean[kc] = 0
         elif self._auto_level.get(kc, 0) > kc and nq >= 32:

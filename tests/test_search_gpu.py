@@ -656,7 +656,7 @@ def test_auto_scan_picks_by_k_and_shape(cuda):
     c, q = _unit(rng, 9000, 128), _unit(rng, 40, 128)
     idx = FlatIndex(128, "ip", cuda)
     idx.add(c)
-    for k, want in ((10, "f16"), (16, "f16"), (100, "split"), (200, "f32")):
+    for k, want in ((10, "f16"), (16, "f16"), (100, "f16"), (128, "f16"), (129, "split"), (500, "split")):
         D, I = idx.search(q, k)
         assert idx.last_scan == want
         Dr, Ir = sr.search_exact(q, c, k)
