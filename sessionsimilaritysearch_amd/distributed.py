@@ -36,10 +36,15 @@ def query_slice(nq: int, world: int, rank: int):
     return rank * per, (rank + 1) * per
 
 
-def gather_query_embeddings(emb_local: torch.Tensor, nq: int, out: torch.Tensor | None = None, group=None):
-    """All ranks' [nq / world, d] slices (``query_slice`` order) -> the full [nq, d] batch on every rank."""
+def gather_query_embeddings(emb_local: torch.Tensor, nq: int, out: torch.Tensor | None = None, group=None,
+                            force_collective: bool = False):
+    """All ranks' [nq / world, d] slices (``query_slice`` order) -> the full [nq, d] batch on every rank.
+    ``force_collective`` issues the all-gather even where it moves nothing new (one rank, or every rank
+    embedded the whole batch and world == 1): the 1-rank RCCL execution of tests / ``bench.py --force-collectives``."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1 or emb_local.shape[0] == nq:
+    if force_collective and dist.is_initialized() and emb_local.shape[0] * world == nq:
+        pass
+    elif world == 1 or emb_local.shape[0] == nq:
         return emb_local
     if out is None:
         out = torch.empty((nq, emb_local.shape[1]), dtype=emb_local.dtype, device=emb_local.device)
@@ -77,12 +82,15 @@ class ShardedFlatIndex:
     first row of the shard).  Every rank returns the full merged result.
     """
 
-    def __init__(self, engine, device, group=None):
+    def __init__(self, engine, device, group=None, force_collectives: bool = False):
         self.engine = engine
         self.device = device
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # one rank normally returns its local result as is; with force_collectives (an initialised process
+        # group required) it takes the all-gather + merge route of the multi-rank path all the same
+        self.exchange = self.world > 1 or (force_collectives and dist.is_initialized())
         self._bufs = {}
 
     def _buffers(self, nq, k):
@@ -106,7 +114,7 @@ class ShardedFlatIndex:
         nq = q.shape[0]
         chunk, pack, pack_all, D, I, status, Do, Io = self._buffers(nq, k)
         self.engine.local_search(q, k, D, I, status)
-        if self.world == 1:
+        if not self.exchange:
             return D, I, status
         dist.all_gather_into_tensor(pack_all, pack, group=self.group)
         self.engine.merge(pack_all, chunk, self.world, nq, k, Do, Io)
@@ -118,7 +126,7 @@ class ShardedFlatIndex:
         chunk, pack, pack_all, D, I, status, Do, Io = self._buffers(nq, k)
         self.engine.local_search(q, k, D, I, status)
         self.engine.fix_unproven(q, k, D, I, status)
-        if self.world == 1:
+        if not self.exchange:
             return D, I
         dist.all_gather_into_tensor(pack_all, pack, group=self.group)
         self.engine.merge(pack_all, chunk, self.world, nq, k, Do, Io)

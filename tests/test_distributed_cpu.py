@@ -95,3 +95,36 @@ def test_sharded_search_equals_unsharded(tmp_path, world, n, k):
     mp.spawn(_worker, args=(world, _free_port(), n, k, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+def _worker_forced(rank, world, port, out_dir):
+    """world size 1 with force_collectives: the one-rank form of the exchange route (what the GPU test and
+    `bench.py --force-collectives` run over RCCL), here over gloo."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(5)
+        q = sr.normalize(rng.standard_normal((9, 16)).astype(np.float32))
+        c = sr.normalize(rng.standard_normal((300, 16)).astype(np.float32))
+        idx = ShardedFlatIndex(OracleEngine(c, 70), torch.device("cpu"), force_collectives=True)
+        plain = ShardedFlatIndex(OracleEngine(c, 70), torch.device("cpu"))
+        tq = torch.from_numpy(q)
+        D, I = idx.search(tq, 5)
+        D2, I2, _ = idx.search_async(tq, 5)
+        Dr, Ir = sr.search_exact(q, c, 5, id_offset=70, threads=1)
+        ok = idx.exchange and not plain.exchange
+        ok = ok and np.array_equal(I.numpy(), Ir) and np.array_equal(D.numpy(), Dr) and np.array_equal(I2.numpy(), Ir)
+        full = torch.arange(12.0).view(6, 2)
+        out = torch.zeros_like(full)
+        got = gather_query_embeddings(full, 6, out, force_collective=True)
+        ok = ok and got is out and torch.equal(out, full)
+        ok = ok and gather_query_embeddings(full, 6, out) is full          # default: one rank returns its input as is
+        open(os.path.join(out_dir, "forced.txt"), "w").write("ok" if ok else "MISMATCH")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_forced_exchange_route(tmp_path):
+    mp.spawn(_worker_forced, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert open(tmp_path / "forced.txt").read() == "ok"

@@ -86,3 +86,25 @@ def test_config_c3_pipeline_small(cuda):
     gt = set(int(v) for v in items[4500 + 0])                             # the full session's items
     p, r = get_p_r(gt, one, 10)
     assert 0.0 <= p <= 1.0 and 0.0 <= r <= 1.0
+
+
+def test_vote_and_p_r_equal_the_reference_run_vectors(cuda):
+    """`sss_knn_item_vote` and `retrieval.get_p_r` against tests/golden/reference_pure.npz: item lists the reference's
+    OWN `get_prediction_by_knn` (test_amazon_filterd.py:59-78) produced for these (D, I, session items) inputs in the
+    build container (tests/golden/make_golden_pure.py), incl. exact weight ties and fewer items than K."""
+    import os
+    from sessionsimilaritysearch_amd.retrieval import SessionItems, get_p_r, knn_item_vote
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_pure.npz"), allow_pickle=False)
+    for tag in z["vote_tags"]:
+        ds = SessionItems(torch.from_numpy(z[f"vote_{tag}_ptr"]).to(cuda), torch.from_numpy(z[f"vote_{tag}_items"].astype(np.int32)).to(cuda))
+        D = torch.from_numpy(z[f"vote_{tag}_D"][None, :]).to(cuda)
+        I = torch.from_numpy(z[f"vote_{tag}_I"][None, :]).to(cuda)
+        K = int(z[f"vote_{tag}_K"])
+        out, status = knn_item_vote(D, I, ds, K)
+        assert int(status.sum().item()) == 0
+        got = [int(v) for v in out[0].cpu().numpy() if v >= 0]
+        assert got == z[f"vote_{tag}_pred"].tolist(), tag
+        assert (out[0, len(got):] == -1).all()
+    for i in range(int(z["pr_cases"])):
+        gt, pred, K = set(z[f"pr{i}_gt"].tolist()), z[f"pr{i}_pred"].tolist(), int(z[f"pr{i}_K"])
+        assert list(get_p_r(gt, pred, K)) == z[f"pr{i}_out"].tolist()

@@ -278,6 +278,30 @@ def test_build_index_metrics_and_error(cuda):
         build_index(emb, "hamming", cuda)
 
 
+def test_normalize_rows_against_the_reference_run_vectors(cuda):
+    """`sss_normalize_rows` (both rules) against outputs of the reference's OWN `normalize` functions
+    (util_amazon_filtered.py:28-31, fine_tune_ours.py:38-40; tests/golden/make_golden_pure.py ran them): floating
+    point, so within the 1e-5 `north_star` states -- in fact to float32 rounding (the reference sums squares in
+    float32 pairwise order, the kernel in its lane order) -- and exactly where the rule is decided by the clip."""
+    import os
+    from sessionsimilaritysearch_amd.index import normalize
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_pure.npz"), allow_pickle=False)
+    for x, y in (("norm_x32", "norm_y32"), ("norm_x1600", "norm_y1600")):
+        got = normalize(z[x].copy())
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, z[y], rtol=2e-6, atol=1e-9)
+        assert np.abs(got - z[y]).max() < 1e-5 * max(1.0, float(np.abs(z[y]).max()))
+        np.testing.assert_allclose(normalize(z[x].copy(), eps=1e-4, rule=1), z["normft_" + y[5:]], rtol=2e-6, atol=1e-9)
+    got = normalize(z["norm_x32"].copy())
+    assert np.array_equal(got[3], z["norm_y32"][3])                      # zero row stays zero
+    assert np.array_equal(got[4], z["norm_y32"][4])                      # below the clip: x / 1e-3, no sum involved
+    np.testing.assert_allclose(normalize(z["norm_v1"].copy()), z["norm_w1"], rtol=2e-6, atol=1e-9)     # 1-D branch
+    assert np.array_equal(normalize(np.ones(4, np.float32)), z["norm_ones4"].astype(np.float32))
+    assert np.array_equal(normalize(np.zeros(8, np.float32)), z["norm_wz"])
+    # float64 input: the reference computes in float64; the device path is float32 (the deployed vectors are float32)
+    np.testing.assert_allclose(normalize(z["norm_x64"].astype(np.float32)), z["norm_y64"], rtol=3e-6, atol=1e-7)
+
+
 def test_normalize_matches_reference_rule(cuda):
     from sessionsimilaritysearch_amd.index import normalize
     assert np.array_equal(normalize(np.ones(4, np.float32)), np.full(4, 0.5, np.float32))  # test_amazon_filterd.py:866
