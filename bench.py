@@ -319,7 +319,9 @@ class Bench:
                 api = "search (synchronous exact API; %d queries were unproven in the async run)" % unproven
                 step = step_sync
                 res, elapsed, _ = timed_region(step_sync, steps, warmup)
-            emb, D, I = res[:3]
+            # snapshot: D / I are the sharded index's own result buffers, which the stage timings below overwrite
+            emb, D, I = res[0], res[1].clone(), res[2].clone()
+            rung_q, exhaustive_q = index.last_rescan_queries, index.last_fallback_queries     # of the last (synchronous) step
             tot_ms, launches = ctypes.c_double(0), ctypes.c_int(0)
             _lib.check(L.sss_profile_read(ctypes.byref(tot_ms), ctypes.byref(launches)), "profile_read")
             L.sss_profile_enable(0)
@@ -387,6 +389,8 @@ class Bench:
                 "recall_at_10": round(sr.recall_at_k(I_got, Ir, k), 6), "ids_bit_exact": bool(np.array_equal(I_got, Ir)),
                 "max_score_err": float(np.abs(D_got - Dr).max()), "recall_queries_checked": nrq, "unproven_queries": unproven,
                 "stage_ms": stage, "incl_graph_build": incl, "collectives_ms": coll,
+                "last_step_rung_queries": rung_q if step is step_sync else None,
+                "last_step_exhaustive_queries": exhaustive_q if step is step_sync else None,
                 "items_bit_exact": items_exact,
                 "index_bytes": {"rows": (hi - lo) * d * (4 if sp.dtype == "f32" else 2), "scan_image": image_bytes},
                 "arithmetic": ("candidate scan: f32 rows as bf16 hi|lo pairs, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 "
@@ -465,6 +469,9 @@ class Bench:
             out["items_bit_exact"] = leg["items_bit_exact"]
         if leg["collectives_ms"] is not None:
             out["collectives_ms"] = leg["collectives_ms"]
+        if leg["last_step_rung_queries"] is not None:
+            out["last_step_rung_queries"] = leg["last_step_rung_queries"]
+            out["last_step_exhaustive_queries"] = leg["last_step_exhaustive_queries"]
         return out
 
     def configs_legs(self, steps, warmup):
@@ -576,6 +583,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the `configs` object (C4 10M x 128 f32 + auto legs, C5 10M x 256 bf16, C3 1M sessions)")
     ap.add_argument("--config-steps", type=int, default=5, help="timed steps per leg of the `configs` object")
+    ap.add_argument("--config-index", type=int, default=2,
+                    help="seed family of the weights / corpus (SURVEY.md 8(d): 1234 + index, 20260000 + index * 100000); the "
+                         "`configs` object uses 4 / 5 / 3 for C4 / C5 / C3")
     ap.add_argument("--force-collectives", action="store_true",
                     help="N = 1 only: create a one-rank RCCL group and run the all-gather + merge route of the multi-rank path")
     args = ap.parse_args()
@@ -605,7 +615,7 @@ def main():
     if c3 and (world != 1 or args.dtype != "f32"):
         raise SystemExit("--workload c3 is the single-GPU f32 configuration")
     B = Bench(args, world, rank, device, dist)
-    sp = Spec("main", 2, args.corpus_rows, args.corpus_source, d=args.d, nq=args.nq, k=args.k, dtype=args.dtype,
+    sp = Spec("main", args.config_index, args.corpus_rows, args.corpus_source, d=args.d, nq=args.nq, k=args.k, dtype=args.dtype,
               workload=args.workload, sample_size=args.sample_size,
               recall_queries=args.recall_queries if not c3 else min(8, args.recall_queries))
 
@@ -651,7 +661,9 @@ def main():
                if m["incl_graph_build"] else {}),
             **({"collectives_ms": m["collectives_ms"]} if m["collectives_ms"] else {}),
             **({"c3": {"sessions": meta["n_sessions"], "index_rows": meta["n_total"], "sample_size": meta["k"], "items_returned": meta["k_items"],
-                       "items_bit_exact": m["items_bit_exact"], "queries_checked": meta["nrq"]}} if c3 else {}),
+                       "items_bit_exact": m["items_bit_exact"], "queries_checked": meta["nrq"],
+                       "last_step_rung_queries": m["last_step_rung_queries"],
+                       "last_step_exhaustive_queries": m["last_step_exhaustive_queries"]}} if c3 else {}),
             "arithmetic": m["arithmetic"],
             "roofline": m["roofline"],
             "cpu_baseline": cpu,
