@@ -131,12 +131,12 @@ int sss_ip_topk_threshold(const void* q, const int32_t* qsel, int64_t nsel, cons
 
 /* LONG rows (the reference's own D = 1600 session vectors, K = 100: pretrain_filtered_amazon.py:281,
  * test_amazon_filterd.py:459,578 -- `index.search(normalize(emb), K)`): any d % 64 == 0 with rows of at most
- * 16384 bytes (d <= 4096 float32, <= 8192 bfloat16), k <= 4096.
+ * 16384 bytes (d <= 4096 float32, <= 8192 bfloat16), k <= 1024 (what the exhaustive path of a status-1 query resolves).
  * A K-tiled MFMA contraction (256 queries x 256 rows per workgroup tile, both operands streamed through LDS in
  * 128-byte slabs) whose top-k rides on thresholds instead of running lists: a few evenly spread row samples of
  * growing size give, level by level, a tighter lower bound of each query's k-th score; the last pass over every
  * row keeps exactly the rows that can still reach that bound and re-scores them all canonically (float64, from
- * `corpus`).  status 0 = exact; 1 = more than 8192 rows could reach the bound (mass ties): re-run through
+ * `corpus`).  status 0 = exact; 1 = more than 8192 rows (4096 for rows beyond 10240 bytes) could reach the bound (mass ties): re-run through
  * sss_ip_topk_exhaustive(_lb) -- column k-1 of such a row of D_out still holds a valid lower bound (or -FLT_MAX).
  * dtype 0: q / corpus float32, scan_image = the scaled float16 image of the corpus (sss_scale_f16; corpus_shift /
  * corpus_resid_norm as for sss_ip_topk_f16; the queries are scaled + rounded to float16 internally).
@@ -187,6 +187,13 @@ int sss_profile_read(double* total_ms, int* launches);
  * out[i, :] = table[ids[i], :]; out row stride ld_out floats (writes slice 0 of the node buffer). */
 int sss_gather_rows(const float* table, const int64_t* ids, int64_t n, int d, float* out,
                     int64_t ld_out, void* stream);
+
+/* use_id_embedding=True of UnifyPoolingGraphLevelEncoder.forward -- model/model.py:288-289:
+ * embedding['product'] = torch.concat((a, b), dim=1), a = the id embedding rows (NodeAsinEmbedding), b = the node's
+ * text features: out[i] = [table[ids[i]] (d_id floats) | feat[i] (d_feat floats) | d_pad zeros], one pass.
+ * feat == NULL writes zeros in its place (d_id == 0 with feat == NULL: a zero-padded row); every width % 4 == 0. */
+int sss_gather_concat_rows(const float* table, const int64_t* ids, int d_id, const float* feat, int64_t ld_feat,
+                           int d_feat, int d_pad, int64_t n, float* out, int64_t ld_out, void* stream);
 
 /* Dense node transform  y[n, m] = x[n, k] * w[m, k]^T (+ bias[m])  on the f32 MFMA.  Replaces
  * the nn.Linear / lazy Linear / GRUCell matmuls inside PyG GATConv (lin_src), GatedGraphConv

@@ -131,13 +131,22 @@ def pos_att_pool(node_q, node_p, q_pos, q_batch, p_cnt, p_pos, p_batch, num_grap
 
 
 def encoder_forward(batch, w, n_layers, self_loops=True, dtype=torch.float32, get_node=False,
-                    query_node_mask=None, product_node_mask=None):
+                    query_node_mask=None, product_node_mask=None, use_id_embedding=False):
     """``UnifyPoolingGraphLevelEncoder.forward`` (reference model/model.py:279-351) with the
-    text encoder replaced by a feature-table lookup (out-of-scope boundary).
-    ``batch`` is a SessionBatch of torch CPU tensors."""
+    text encoder replaced by a feature-table lookup or by precomputed ``.feat`` rows on the node stores
+    (out-of-scope boundary).  ``batch`` is a SessionBatch of torch CPU tensors.
+    ``use_id_embedding`` (model/model.py:288-291): ``embedding['product'] = torch.concat((a, b), dim=1)`` with
+    ``a = product_node_embedder(x)`` (``item_table``, NodeAsinEmbedding) and ``b`` the product text features
+    (``.feat`` or the ``item_text_table`` stand-in); False: ``embedding['product'] = b``."""
     w = {k: v.to(dtype) if v.is_floating_point() else v for k, v in w.items()}
-    xq = embedding_lookup(w["query_table"], batch["query"].x)
-    xp = embedding_lookup(w["item_table"], batch["product"].x)
+    q_feat, p_feat = getattr(batch["query"], "feat", None), getattr(batch["product"], "feat", None)
+    xq = q_feat.to(dtype) if q_feat is not None else embedding_lookup(w["query_table"], batch["query"].x)
+    if use_id_embedding:
+        a = embedding_lookup(w["item_table"], batch["product"].x)
+        b = p_feat.to(dtype) if p_feat is not None else embedding_lookup(w["item_text_table"], batch["product"].x)
+        xp = torch.concat((a, b), dim=1)
+    else:
+        xp = p_feat.to(dtype) if p_feat is not None else embedding_lookup(w["item_table"], batch["product"].x)
     if query_node_mask is not None:
         xq = xq * query_node_mask.view(-1, 1).to(dtype)
     if product_node_mask is not None:

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "sss_profile_enable": (c_int, [c_int]),
     "sss_profile_read": (c_int, [c_void_p, c_void_p]),
     "sss_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "sss_gather_concat_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_int64,
+                                       c_void_p]),
     "sss_linear": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
                            c_int, c_int, c_void_p]),
     "sss_gat_aggregate": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,

@@ -57,6 +57,7 @@ int normalize_rows(float*, long, int, long, float, int, hipStream_t);
 int row_norm_max(const void*, long, int, int, float*, hipStream_t);
 int f32_to_bf16(const float*, long, unsigned short*, hipStream_t);
 int gather_rows(const float*, const long*, long, int, float*, long, hipStream_t);
+int gather_concat_rows(const float*, const long*, int, const float*, long, int, int, long, float*, long, hipStream_t);
 int linear_f32(const float*, long, const float*, long, const float*, float*, long, long, int, int, hipStream_t);
 int gat_aggregate(const float*, long, const float*, long, const float*, long, const int*, const int*, long, int,
                   const float*, int, long, float*, long, hipStream_t);
@@ -198,6 +199,12 @@ int sss_profile_read(double* total_ms, int* launches) { return sss::profile_read
 int sss_gather_rows(const float* table, const int64_t* ids, int64_t n, int d, float* out, int64_t ld_out,
                     void* stream) {
     return sss::gather_rows(table, reinterpret_cast<const long*>(ids), n, d, out, ld_out, ST(stream));
+}
+
+int sss_gather_concat_rows(const float* table, const int64_t* ids, int d_id, const float* feat, int64_t ld_feat, int d_feat,
+                           int d_pad, int64_t n, float* out, int64_t ld_out, void* stream) {
+    return sss::gather_concat_rows(table, reinterpret_cast<const long*>(ids), d_id, feat, ld_feat, d_feat, d_pad, n, out, ld_out,
+                                   ST(stream));
 }
 
 int sss_linear(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,

@@ -17,6 +17,8 @@
 
 namespace sss {
 
+int normalize_rows(float* x, long n, int d, long ld, float eps, int rule, hipStream_t st);    // rowops.hip
+
 constexpr int LT = 64;      // GEMM tile rows (X) and columns (W rows): see k_linear_grouped below
 
 int linear_grouped(LinBatch& b, hipStream_t st);
@@ -179,14 +181,14 @@ __global__ __launch_bounds__(256) void k_segment_pool(const float* __restrict__ 
                                                       const float* __restrict__ A, long ld_a,
                                                       const float* __restrict__ bcoarse, long ld_b,
                                                       const float* __restrict__ watt,
-                                                      float* __restrict__ out, long ld_out) {
+                                                      float* __restrict__ out, long ld_out, int reduce_sum = 0) {
     const int sub = threadIdx.x % LPR;
     const long per_block = 256 / LPR;
     const int nv = D / 4;
     for (long g = (long)blockIdx.x * per_block + threadIdx.x / LPR; g < n_graphs; g += (long)gridDim.x * per_block) {
         const int p0 = pptr[g], p1 = pptr[g + 1], q0 = qptr[g], q1 = qptr[g + 1];
         const int cnt = (p1 - p0) + (q1 - q0);
-        const float invc = 1.f / (float)(cnt > 0 ? cnt : 1);
+        const float invc = reduce_sum ? 1.f : 1.f / (float)(cnt > 0 ? cnt : 1);     // sum: SRGNN_Pooling's global_add_pool
         // Wide rows with attention (the reference's D = 1600: 400 float4 columns over 64 lanes): ONE sweep over the
         // graph's nodes -- a node's attention weight is computed once and applied to all of the lane's (up to eight)
         // columns; the column-chunked sweeps below would recompute it, and re-read the node's A row, per chunk.
@@ -505,7 +507,10 @@ __global__ __launch_bounds__(256, 2) void k_linear_grouped(const LinBatch B) {
             else if (act == 2) v = tanhf(v);
             else if (act == 3) v = v > 0.f ? 1.f : v < 0.f ? -1.f : v;     // torch.sign (0 and NaN pass through)
             else if (act == 4) v = tanhf(tanhf(v));
-            if (post_s) v = fmaxf(v * ps + pt, 0.f);                        // two roundings, as bn(x) in eval mode then relu
+            if (post_s) {
+#pragma clang fp contract(off)                                               // multiply, round, add, round: no fused fma here
+                v = fmaxf(v * ps + pt, 0.f);                                // bn(x) in eval mode as scale / shift, then relu
+            }
             if (row < N) Y[row * ldy + col] = v;
         }
     }
@@ -922,12 +927,21 @@ int pool_expand_mean(const float* lin_p, const float* lin_q, long ld_lin, const 
 int pool_attention(const float* node, long ld_node, const float* Aa, long ld_a, const float* Bc, long ld_b, const float* watt,
                    const int* pptr, const int* qptr, long n_clicks, long n_graphs, int D, int normalize, float eps, int reduce_sum,
                    float* out, long ld_out, hipStream_t st) {
-    if (n_graphs < 0 || D <= 0 || D % 4 || D > 256 || ld_node % 4 || ld_a % 4 || ld_b % 4 || ld_out % 4 || ld_out < D) {
-        set_error("pool_attention: need D %% 4 == 0, D <= 256, 16-byte aligned row strides");
+    if (n_graphs < 0 || D <= 0 || D % 4 || ld_node % 4 || ld_a % 4 || ld_b % 4 || ld_out % 4 || ld_out < D) {
+        set_error("pool_attention: need D %% 4 == 0, 16-byte aligned row strides");
         return SSS_EINVAL;
     }
     if (n_graphs == 0) return SSS_OK;
     const int lpr = lanes_for(D);
+    if (D > 256) {
+        // rows wider than one float4 column per lane (the reference's gnn_nout = 800, config.py:16): the column-chunked
+        // sweep of k_segment_pool, which computes a node's attention weight once for all of a lane's columns
+        SSS_LPR_SWITCH(lpr, hipLaunchKernelGGL(k_segment_pool<L>, dim3(grid_rows(n_graphs, L)), dim3(256), 0, st, node, ld_node,
+                                               pptr, qptr, n_clicks, n_graphs, D, Aa, ld_a, Bc, ld_b, watt, out, ld_out, reduce_sum));
+        const int rc = check_launch("k_segment_pool");
+        if (rc || !normalize) return rc;
+        return normalize_rows(out, n_graphs, D, ld_out, eps, 0, st);
+    }
     const long per = 256 / lpr;
     SSS_LPR_SWITCH(lpr, hipLaunchKernelGGL(k_pool_attention<L>, dim3((unsigned)((n_graphs + per - 1) / per)), dim3(256), 0, st, node,
                                            ld_node, Aa, ld_a, Bc, ld_b, watt, pptr, qptr, n_clicks, n_graphs, D, normalize, eps,

@@ -192,6 +192,34 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ t
     }
 }
 
+// use_id_embedding=True of the reference encoder (model/model.py:288-289): embedding['product'] =
+// concat(id_embedding(x), text_features) -- out[i] = [table[ids[i]] (d_id floats) | feat[i] (d_f floats) | pad zeros],
+// one pass, one lane group per row.  feat == nullptr writes zeros there (query rows padded to the product width).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_gather_concat_rows(const float* __restrict__ table, const long* __restrict__ ids,
+                                                            int d_id, const float* __restrict__ feat, long ld_feat, int d_f,
+                                                            int d_pad, long n, float* __restrict__ out, long ld_out) {
+    const int sub = threadIdx.x % LPR;
+    const long rows_per_block = 256 / LPR;
+    const int nv_id = d_id / 4, nv_f = d_f / 4, nv_pad = d_pad / 4;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long row = (long)blockIdx.x * rows_per_block + threadIdx.x / LPR; row < n;
+         row += (long)gridDim.x * rows_per_block) {
+        float4* dst = reinterpret_cast<float4*>(out + row * ld_out);
+        if (nv_id) {
+            const float4* src = reinterpret_cast<const float4*>(table + ids[row] * (long)d_id);
+            for (int i = sub; i < nv_id; i += LPR) dst[i] = src[i];
+        }
+        if (feat) {
+            const float4* f = reinterpret_cast<const float4*>(feat + row * ld_feat);
+            for (int i = sub; i < nv_f; i += LPR) dst[nv_id + i] = f[i];
+        } else {
+            for (int i = sub; i < nv_f; i += LPR) dst[nv_id + i] = zero;
+        }
+        for (int i = sub; i < nv_pad; i += LPR) dst[nv_id + nv_f + i] = zero;
+    }
+}
+
 static int lanes_per_row(int d) {
     const int nv = d / 4;
     int l = 1;
@@ -301,6 +329,20 @@ int gather_rows(const float* table, const long* ids, long n, int d, float* out, 
     const int lpr = lanes_per_row(d);
     SSS_DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_gather_rows<L>, dim3(grid_for(n, L)), dim3(256), 0, st, table, ids, n, d, out, ld_out));
     return check_launch("k_gather_rows");
+}
+
+int gather_concat_rows(const float* table, const long* ids, int d_id, const float* feat, long ld_feat, int d_f, int d_pad,
+                       long n, float* out, long ld_out, hipStream_t st) {
+    if (n < 0 || d_id < 0 || d_f < 0 || d_pad < 0 || d_id % 4 || d_f % 4 || d_pad % 4 || d_id + d_f + d_pad <= 0 ||
+        ld_out % 4 || ld_out < d_id + d_f + d_pad || (feat && (ld_feat % 4 || ld_feat < d_f)) || (d_id > 0 && (!table || !ids))) {
+        set_error("gather_concat_rows: need widths %% 4 == 0, ld_out >= d_id + d_f + d_pad, 16-byte aligned row strides");
+        return SSS_EINVAL;
+    }
+    if (n == 0) return SSS_OK;
+    const int lpr = lanes_per_row(d_id + d_f + d_pad);
+    SSS_DISPATCH_LPR(lpr, hipLaunchKernelGGL(k_gather_concat_rows<L>, dim3(grid_for(n, L)), dim3(256), 0, st, table, ids, d_id, feat,
+                                             ld_feat, d_f, d_pad, n, out, ld_out));
+    return check_launch("k_gather_concat_rows");
 }
 
 }  // namespace sss

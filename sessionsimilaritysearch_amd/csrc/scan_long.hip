@@ -275,6 +275,10 @@ __global__ __launch_bounds__(512, 2) void k_scan_long(const LongArgs A) {
 
 // ------------------------------------------------------------------------------ host side
 constexpr int LONG_CAP = 8192;      // rows kept per query (k_select_all sorts them in 64 KB of LDS)
+constexpr int LONG_MAX_K = 1024;    // what the exhaustive kernels -- the path of a query left at status 1 -- can resolve
+// k_select_all keeps 2 x cap keys + the exact query row + its staging tile in LDS: rows beyond 10240 bytes
+// (f32 d > 2560, bf16 d > 5120) leave room for half the capacity only.
+static int long_cap(int d, int exact_dtype) { return d * elem_bytes(exact_dtype) > 10240 ? LONG_CAP / 2 : LONG_CAP; }
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static bool long_shape_ok(int d, int exact_dtype, int scan_dtype) {
@@ -302,7 +306,8 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     if (!long_shape_ok(d, exact_dtype, scan_dtype)) { set_error("ip_topk_long: need dtype 0 / 1, d %% 64 == 0 and rows of at most 16384 bytes (got dtype %d d %d)", exact_dtype, d); return SSS_EINVAL; }
     if (!c_scan || (reinterpret_cast<uintptr_t>(c_scan) & 15)) { set_error("ip_topk_long: scan image missing or not 16-byte aligned"); return SSS_EINVAL; }
     if (n >= (1L << 31) - 1024 || nq >= (1L << 31)) { set_error("ip_topk_long: n and nq must be < 2^31"); return SSS_EINVAL; }
-    if (2 * k > LONG_CAP) { set_error("ip_topk_long: k too large (max %d)", LONG_CAP / 2); return SSS_EINVAL; }
+    if (k > LONG_MAX_K) { set_error("ip_topk_long: k too large (max %d)", LONG_MAX_K); return SSS_EINVAL; }
+    const int cap = long_cap(d, exact_dtype);
     if (reinterpret_cast<uintptr_t>(ws) & 255) { set_error("ip_topk_long: workspace must be 256-byte aligned"); return SSS_EINVAL; }
     const size_t need = ip_topk_long_workspace_bytes(nq, n, d, exact_dtype);
     if (ws_bytes < need) { set_error("ip_topk_long: workspace %zu < %zu", ws_bytes, need); return SSS_EWORKSPACE; }
@@ -333,9 +338,9 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     // that the last sample is as small as it can be (1M x 1600, K = 100: 32, 353, 3907 tiles -- the samples add ~10 % to
     // the matrix work; it was 1, 24, 488, 3907).  Intermediate levels read no row at all (k_bound_from_scan).
     const int total_tiles = (int)((n + LT_ROWS - 1) / LT_ROWS);
-    int fmax = LONG_CAP / (4 * k);
+    int fmax = cap / (4 * k);
     if (fmax < 2) fmax = 2;
-    int first = LONG_CAP / LT_ROWS;
+    int first = cap / LT_ROWS;
     if (first > total_tiles) first = total_tiles;
     int level_tiles[40];
     int levels = 0;
@@ -353,12 +358,12 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
         level_tiles[levels++] = first;
     }
     ThrArgs t;
-    t.Q = q; t.C = c_exact; t.qsel = qsel; t.nsel = (int)nq; t.d = d; t.dtype = exact_dtype; t.k = k; t.cap = LONG_CAP;
+    t.Q = q; t.C = c_exact; t.qsel = qsel; t.nsel = (int)nq; t.d = d; t.dtype = exact_dtype; t.k = k; t.cap = cap;
     t.scan_dtype = scan_dtype; t.corpus_shift = corpus_shift; t.corpus_resid = corpus_resid; t.corpus_max_norm = corpus_max_norm;
     t.id_offset = id_offset; t.thr = thr; t.cnt = cnt; t.cand = cand; t.D_out = D_out; t.I_out = I_out; t.status = status;
     LongArgs a;
     a.Qimg = q_scan; a.C = c_scan; a.nq = (int)nq; a.n = (int)n; a.d = d; a.G = (int)((nq + LT_Q - 1) / LT_Q);
-    a.total_tiles = total_tiles; a.cap = LONG_CAP; a.thr = thr; a.cnt = cnt; a.cand = cand;
+    a.total_tiles = total_tiles; a.cap = cap; a.thr = thr; a.cnt = cnt; a.cand = cand;
     static bool attr_done[MAX_DEVICES][2] = {};
     const int dev = current_device();
     for (int lv = levels - 1; lv >= 0; --lv) {

@@ -30,7 +30,12 @@ ALPHA_PAD = 32          # extra output columns of the fused node transforms (2 u
 
 @dataclass
 class EncoderConfig:
-    d_in: int = 128                 # node input feature width
+    d_in: int = 128                 # node input feature width (query nodes; product nodes too unless d_id > 0)
+    # use_id_embedding=True of the reference (model/model.py:264,288-289): embedding['product'] =
+    # concat(id_embedding(x), text_features) -- d_id is the width of the id embedding (``item_table``), the text
+    # features (d_in wide) come from ``data['product'].feat`` or the ``item_text_table`` stand-in.  0 = False, what
+    # the deployed checkpoints use (pretrain_filtered_amazon.py:277,287).
+    d_id: int = 0
     h: int = 128                    # GNN width (reference CFG.gnn_nout = 800, config.py:16)
     n_layers: int = 2               # reference CFG.gnn_nlayers = 3, config.py:21
     d_out: int = 128                # session vector width D (reference gnn_nout * 2 = 1600)
@@ -42,13 +47,21 @@ class EncoderConfig:
     self_loop_rule: str = "pyg_bipartite_global"
 
     @property
-    def node_width(self) -> int:
+    def d_p(self) -> int:               # product-node input width
+        return self.d_id + self.d_in
+
+    @property
+    def node_width(self) -> int:        # W of the product node outputs (and of the query ones when d_id == 0)
+        return self.d_p + self.n_layers * self.h
+
+    @property
+    def node_width_q(self) -> int:
         return self.d_in + self.n_layers * self.h
 
     def validate(self):
-        if self.d_in % 32 or self.h % 32 or self.d_out % 32:
-            raise ValueError("d_in, h and d_out must be multiples of 32")
-        if self.d_in > self.h:
+        if self.d_in % 32 or self.h % 32 or self.d_out % 32 or self.d_id % 32 or self.d_id < 0:
+            raise ValueError("d_in, d_id, h and d_out must be multiples of 32")
+        if self.d_p > self.h:
             raise ValueError("GatedGraphConv needs d_in <= h (the reference hits the same ValueError)")
         if self.d_out <= self.max_seq_len:
             raise ValueError("d_out must exceed max_seq_len")
@@ -69,14 +82,18 @@ def init_weights(cfg: EncoderConfig, seed: int, random_bias: bool = True, tables
     h, D, P, W = cfg.h, cfg.d_out, cfg.max_seq_len, cfg.node_width
     w = {}
     if tables:
-        w["item_table"] = torch.randn((cfg.n_items, cfg.d_in), generator=g)
+        w["item_table"] = torch.randn((cfg.n_items, cfg.d_id if cfg.d_id else cfg.d_in), generator=g)
         w["query_table"] = torch.randn((cfg.n_query, cfg.d_in), generator=g)
+        if cfg.d_id:
+            w["item_text_table"] = torch.randn((cfg.n_items, cfg.d_in), generator=g)
     for l in range(cfg.n_layers):
         din = cfg.d_in if l == 0 else h
         for name in ("gat_qp", "gat_pq"):
-            gl = math.sqrt(6.0 / (din + h))
-            w[f"{name}.{l}.lin_src"] = _uniform(g, (h, din), gl)
-            w[f"{name}.{l}.lin_dst"] = _uniform(g, (h, din), gl)
+            # lazy (-1, -1) input widths: the source / target node types differ in width when d_id > 0
+            d_src = din if (l > 0 or name == "gat_qp") else cfg.d_p
+            d_dst = din if (l > 0 or name == "gat_pq") else cfg.d_p
+            w[f"{name}.{l}.lin_src"] = _uniform(g, (h, d_src), math.sqrt(6.0 / (d_src + h)))
+            w[f"{name}.{l}.lin_dst"] = _uniform(g, (h, d_dst), math.sqrt(6.0 / (d_dst + h)))
             ga = math.sqrt(6.0 / (1 + h))
             w[f"{name}.{l}.att_src"] = _uniform(g, (h,), ga)
             w[f"{name}.{l}.att_dst"] = _uniform(g, (h,), ga)
@@ -87,9 +104,9 @@ def init_weights(cfg: EncoderConfig, seed: int, random_bias: bool = True, tables
         w[f"ggc.{l}.w_hh"] = _uniform(g, (3 * h, h), b)
         w[f"ggc.{l}.b_ih"] = _uniform(g, (3 * h,), b)
         w[f"ggc.{l}.b_hh"] = _uniform(g, (3 * h,), b)
-    bw = 1.0 / math.sqrt(W)
-    for name in ("pool.query_lin", "pool.product_lin"):
-        w[name + ".w"] = _uniform(g, (D - P, W), bw)
+    for name, wd in (("pool.query_lin", cfg.node_width_q), ("pool.product_lin", W)):
+        bw = 1.0 / math.sqrt(wd)
+        w[name + ".w"] = _uniform(g, (D - P, wd), bw)
         w[name + ".b"] = _uniform(g, (D - P,), bw)
     w["pool.pos_emb"] = torch.randn((P, P), generator=g)
     bd = 1.0 / math.sqrt(D)
@@ -155,6 +172,15 @@ class SessionEncoder:
         if not torch.cuda.is_available():
             raise _lib.SssError("no HIP device available: the encoder runs on MI355X only")
         _lib.lib()
+        # use_id_embedding (d_id > 0): internally BOTH node types run at the product width d_p = d_id + d_in -- query
+        # feature rows are zero-padded behind their d_in columns and every weight that reads them gets zero columns
+        # there (`_internal_weights`), which leaves the arithmetic of the reference's mixed-width model unchanged
+        # (a zero column adds exact zeros) and lets every kernel keep ONE input width.
+        self.user_cfg = cfg
+        self.d_id, self.d_feat = cfg.d_id, cfg.d_in
+        if cfg.d_id:
+            weights = self._internal_weights(cfg, weights)
+            cfg = EncoderConfig(**{**cfg.__dict__, "d_in": cfg.d_p, "d_id": 0})
         self.cfg = cfg
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.use_edge_weight = use_edge_weight      # the deployed path passes none (model/model.py:317)
@@ -177,6 +203,27 @@ class SessionEncoder:
         return self.forward(*a, **kw)
 
     # ------------------------------------------------------------------ weight preparation
+    @staticmethod
+    def _internal_weights(cfg, w):
+        """Reference-shaped weights of a use_id_embedding model -> the single-width internal form: product rows are
+        [id embedding | text features] as the reference concatenates them (model/model.py:289), query rows
+        [text features | d_id zeros]."""
+        dq, did, h = cfg.d_in, cfg.d_id, cfg.h
+        pad_cols = lambda t: torch.cat([t, t.new_zeros(t.shape[0], did)], dim=1)
+        out = dict(w)
+        out["id_table"] = w["item_table"]                           # kept for batches that bring their own text features
+        if "item_text_table" in w:
+            out["item_table"] = torch.cat([w["item_table"], w["item_text_table"]], dim=1)
+        else:
+            del out["item_table"]
+        if "query_table" in w:
+            out["query_table"] = pad_cols(w["query_table"])
+        out["gat_qp.0.lin_src"] = pad_cols(w["gat_qp.0.lin_src"])   # reads query rows
+        out["gat_pq.0.lin_dst"] = pad_cols(w["gat_pq.0.lin_dst"])
+        ql = w["pool.query_lin.w"]
+        out["pool.query_lin.w"] = torch.cat([ql[:, :dq], ql.new_zeros(ql.shape[0], did), ql[:, dq:]], dim=1)
+        return out
+
     def _prepare(self, w):
         cfg, dev = self.cfg, self.device
         h = cfg.h
@@ -184,6 +231,7 @@ class SessionEncoder:
         d = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
         self.item_table = d(w["item_table"]) if "item_table" in w else None
         self.query_table = d(w["query_table"]) if "query_table" in w else None
+        self.id_table = d(w["id_table"]) if "id_table" in w else None      # use_id_embedding: the [V, d_id] NodeAsinEmbedding
         self.layers = []
         for l in range(cfg.n_layers):
             qp = {k: w[f"gat_qp.{l}.{k}"] for k in ("lin_src", "lin_dst", "att_src", "att_dst", "bias")}
@@ -281,7 +329,8 @@ class SessionEncoder:
         pb.q_feat = getattr(q, "feat", None)
         pb.p_feat = getattr(p, "feat", None)
         pb.q_ids = None if pb.q_feat is not None else q.x.to(dev, torch.int64).contiguous()
-        pb.p_ids = None if pb.p_feat is not None else p.x.to(dev, torch.int64).contiguous()
+        # (use_id_embedding: the product ids index the id embedding even when the text features are given)
+        pb.p_ids = None if (pb.p_feat is not None and not self.d_id) else p.x.to(dev, torch.int64).contiguous()
         ei = data.edge_index_dict
         # the PyG self-loop rewrite is applied inside the aggregation kernels (n_self_loop)
         pb.n_self_loop = min(pb.Nq, pb.Np) if cfg.self_loop_rule == "pyg_bipartite_global" else 0
@@ -378,7 +427,8 @@ class SessionEncoder:
             probes += [(pb.pos_id.max(), self.cfg.max_seq_len, False)]
             if check_min_pos:
                 probes += [(pb.pos_id.min(), None, True)]
-        for ids, table in ((pb.p_ids, self.item_table), (pb.q_ids, self.query_table)):
+        p_table = self.id_table if (self.d_id and getattr(pb, "p_feat", None) is not None) else self.item_table
+        for ids, table in ((pb.p_ids, p_table), (pb.q_ids, self.query_table)):
             if ids is not None and ids.numel() and table is not None:
                 probes += [(ids.max(), int(table.shape[0]), False), (ids.min(), None, True)]
         if not probes:
@@ -388,11 +438,22 @@ class SessionEncoder:
             if (is_min and v < 0) or (not is_min and v >= bound):
                 raise IndexError("index out of range in self")
 
-    def _features(self, ids, feat, table, n, buf=None):
+    def _features(self, ids, feat, table, n, buf=None, product=False):
         W = self.cfg.node_width
         if buf is None:
             buf = torch.empty((n, W), dtype=torch.float32, device=self.device)
-        if feat is not None:
+        if feat is not None and self.d_id:
+            # use_id_embedding (model/model.py:288-289): product rows = [id_table[x] | feat], query rows = [feat | zeros]
+            f = feat.to(self.device, torch.float32)
+            if f.dim() != 2 or f.shape[1] != self.d_feat or f.stride(1) != 1 or f.stride(0) % 4:
+                f = f.reshape(n, self.d_feat).contiguous()
+            if product and (self.id_table is None or ids is None):
+                raise _lib.SssError("use_id_embedding: product nodes need their item ids (.x) and the id table")
+            rc = _lib.lib().sss_gather_concat_rows(self.id_table.data_ptr() if product else 0, ids.data_ptr() if product else 0,
+                                                   self.d_id if product else 0, f.data_ptr(), f.stride(0), self.d_feat,
+                                                   0 if product else self.d_id, n, buf.data_ptr(), buf.stride(0), self._st())
+            _lib.check(rc, "sss_gather_concat_rows")
+        elif feat is not None:
             buf[:, :self.cfg.d_in] = feat.to(self.device, torch.float32)
         else:
             if table is None:
@@ -539,7 +600,7 @@ class SessionEncoder:
         gather = pb.q_feat is None and pb.p_feat is None and not masked
         if not gather:      # features given / masked inputs: materialise slice 0 first (per-op kernels)
             self._features(pb.q_ids, pb.q_feat, self.query_table, pb.Nq, NQ)
-            self._features(pb.p_ids, pb.p_feat, self.item_table, pb.Np, NP)
+            self._features(pb.p_ids, pb.p_feat, self.item_table, pb.Np, NP, product=True)
             if query_node_mask is not None:
                 NQ[:, :cfg.d_in] *= query_node_mask.to(dev, torch.float32).view(-1, 1)
             if product_node_mask is not None:
@@ -578,7 +639,7 @@ class SessionEncoder:
             return self._pack(out, NQ, NP, get_node, get_token)
 
         NQ = self._features(pb.q_ids, pb.q_feat, self.query_table, Nq)   # [Nq, W]; slice 0 = input features
-        NP = self._features(pb.p_ids, pb.p_feat, self.item_table, Np)    # embedding lookup (NodeAsinEmbedding)
+        NP = self._features(pb.p_ids, pb.p_feat, self.item_table, Np, product=True)    # embedding lookup (NodeAsinEmbedding)
         if query_node_mask is not None:                   # model/model.py:293-296 (None at inference)
             NQ[:, :cfg.d_in] *= query_node_mask.to(dev, torch.float32).view(-1, 1)
         if product_node_mask is not None:
@@ -650,8 +711,9 @@ class SessionEncoder:
             normalize_(out)
         return self._pack(out, NQ, NP, get_node, get_token)
 
-    @staticmethod
-    def _pack(out, NQ, NP, get_node, get_token):
+    def _pack(self, out, NQ, NP, get_node, get_token):
+        if self.d_id and get_node:      # the reference's query node rows are d_in + L h wide: drop the internal pad columns
+            NQ = torch.cat([NQ[:, :self.d_feat], NQ[:, self.d_feat + self.d_id:]], dim=1)
         node_embedding = {"query": NQ, "product": NP}
         session_level_token_emb = {}            # the cross-attention branch is commented out upstream
         if not get_node and not get_token:

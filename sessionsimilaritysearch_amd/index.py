@@ -35,10 +35,12 @@ AUTO_ESCALATE = 0.005
 AUTO_DECAY_SEARCHES = 64        # clean searches at an escalated level before the class steps back down one scan
 _LADDER = ("f16", "split", "f32")
 FUSED_MAX_K = 500
-LONG_MAX_K = 4096                                                # sss_ip_topk_long: k <= capacity / 2
+LONG_MAX_K = 1024                                                # sss_ip_topk_long: what its exhaustive fallback resolves
 LONG_MAX_ROW_BYTES = 16384
 DTYPE_CODE = {"f32": 0, "bf16": 1}                               # include/sss.h: dtype
 _EXHAUSTIVE_WS_BYTES = 1 << 30
+SEARCH_CHUNK = 65536             # queries per fused call of search_device (workspace 16 KB per query)
+SEARCH_CHUNK_LONG = 16384        # ... on the long-row path (64 KB per query)
 
 
 def _dev(device=None):
@@ -122,11 +124,12 @@ class FlatIndex:
     ``"split"`` keeps each element as a bfloat16 hi/lo pair (same bytes as the f32 row) and scans
     with three bf16 MFMA passes -- error <= ~2^-14 |q||c|;
     ``"f32"`` scans the float32 rows on the f32 MFMA (error ~ d 2^-24) and needs no second image;
-    ``"auto"`` (default) takes "f16" for k <= 16 where the shape allows, "split" up to k = 128 and
-    "f32" beyond (the scores around rank k lie closer together as k grows), and moves a k class one
-    scan up when a search left more than 0.5 % of its queries (at least 4) unproven (back down after 64
-    clean searches).  Images are built on first use (``prepare(k)`` does it ahead of time) and extended
-    as rows are added.
+    ``"auto"`` (default) takes "f16" for k <= 128 where the shape allows and "split" up to k = 500 (every k
+    the fused path serves; the scores around rank k lie closer together as k grows); "f32" is reached by
+    escalation only: a k class moves one scan up when a search left more than 0.5 % of its queries (at least
+    4) unproven, the step is taken back (and the class pinned) when the slower scan proves no more of them,
+    and a class steps back down after 64 CONSECUTIVE clean searches.  Images are built on first use
+    (``prepare(k)`` does it ahead of time) and extended as rows are added.
 
     Queries a scan leaves unproven are resolved in two further stages, both exact: the THRESHOLD RUNG
     (``search_threshold``: one more matrix-core scan for just those queries that keeps every row able to
@@ -148,6 +151,7 @@ class FlatIndex:
         self.last_scan = None           # the scan the last fused search used
         self._auto_level = {}           # scan="auto": k class -> lowest ladder level still allowed
         self._auto_clean = {}           # scan="auto": k class -> consecutive clean searches at the escalated level
+        self._auto_rows = 0             # scan="auto": corpus size when a class last escalated
         self.d = int(d)
         self.metric = metric
         self.dtype = dtype
@@ -188,8 +192,11 @@ class FlatIndex:
         self._store[n_old:n_old + x.shape[0]] = x
         self._xb = self._store[:n_old + x.shape[0]]
         self._norm_max(x)
-        self._auto_level.clear()        # a different corpus: the escalation was earned on the old one
-        self._auto_clean.clear()
+        # streaming adds keep what the searches have learned about this corpus; only once it has doubled since
+        # an escalation was earned is that treated as a different corpus (adopt() always resets)
+        if self._auto_level and self.ntotal > 2 * max(1, self._auto_rows):
+            self._auto_level.clear()
+            self._auto_clean.clear()
 
     def scan_for(self, k: int) -> str:
         """Which candidate scan a fused search for k results uses ("" = none: exhaustive path)."""
@@ -261,9 +268,10 @@ class FlatIndex:
             if up:
                 self._auto_clean[("probe", kc)] = (_LADDER.index(self.last_scan), share)
                 self._auto_level[kc] = _LADDER.index(up)
+                self._auto_rows = self.ntotal
             self._auto_clean[kc] = 0
         elif self._auto_level.get(kc, 0) > kc and nq >= 32:
-            self._auto_clean[kc] = self._auto_clean.get(kc, 0) + (1 if bad == 0 else 0)
+            self._auto_clean[kc] = self._auto_clean.get(kc, 0) + 1 if bad == 0 else 0      # consecutive: any unproven query restarts the count
             if self._auto_clean[kc] >= AUTO_DECAY_SEARCHES:
                 self._auto_level[kc] -= 1
                 self._auto_clean[kc] = 0
@@ -441,7 +449,15 @@ class FlatIndex:
             return "native" if self.d in FUSED_DIMS[self.dtype] else ""
         if not any(self._scan_served(s) for s in _LADDER):
             return ""                            # long rows: their scan IS a threshold scan; what it leaves is mass ties
-        if self.scan in ("auto", "f16") and self._scan_served("f16"):
+        if self.scan == "auto":
+            # an image that is already complete beats building another one (n * d * 2 bytes) for a handful of queries
+            f16_ready = self._f16 is not None and self._f16_done == self.ntotal
+            split_ready = self._split is not None and self._split_done == self.ntotal
+            if self._scan_served("f16") and (f16_ready or not split_ready):
+                return "f16"
+            if split_ready and self._scan_served("split"):
+                return "split"
+        if self.scan == "f16" and self._scan_served("f16"):
             return "f16"
         if self.scan == "split" and self._scan_served("split"):
             return "split"
@@ -535,9 +551,19 @@ class FlatIndex:
         if self.d % (4 if self.dtype == "f32" else 8):
             raise _lib.SssError("d must be a multiple of 4 (f32) / 8 (bf16)")
         if self.fused_ok(k):
+            # the per-query workspace is 16 KB (fused scans) to 64 KB (long rows, threshold rung): the reference hands
+            # `index.search` its whole test set at once (test_amazon_filterd.py:578), so large batches go in chunks
+            step = SEARCH_CHUNK_LONG if self.scan_for(k) == "long" else SEARCH_CHUNK
             status = torch.empty((nq,), dtype=torch.int32, device=self.device)
-            self.search_fused(q, k, (D, I, status))
-            self.fix_unproven(q, k, D, I, status)
+            rescans = fallbacks = 0
+            for lo in range(0, nq, step):
+                hi = min(nq, lo + step)
+                part = (D[lo:hi], I[lo:hi], status[lo:hi])
+                self.search_fused(q[lo:hi], k, part)
+                self.fix_unproven(q[lo:hi], k, *part)
+                rescans += self.last_rescan_queries
+                fallbacks += self.last_fallback_queries
+            self.last_rescan_queries, self.last_fallback_queries = rescans, fallbacks
         else:
             self.last_fallback_queries = nq
             self.search_exhaustive(q, k, D, I)

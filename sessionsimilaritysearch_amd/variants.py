@@ -16,8 +16,9 @@ CSR-by-target + segment kernels:
 
 Every arithmetic step runs in ``libsss.so`` (``sss_csr_mean``, ``sss_segment_reduce``,
 ``sss_attention_dot_pool``, ``sss_pool_attention``, ``sss_linear_grouped``); torch owns memory only.
-Weights are flat ``{name: tensor}`` dicts; conv / pool widths must be multiples of 32 and <= 256, the MLP /
-binarize heads take any width (the reference's 1600 -> 3000 -> 2000 -> 250).
+Weights are flat ``{name: tensor}`` dicts; conv / pool widths are multiples of 32 up to 2048 (the reference runs them at
+``gnn_nout = 800``, config.py:15-16: rows wider than 256 floats are walked in column chunks), the MLP / binarize heads
+take any width (the reference's 1600 -> 3000 -> 2000 -> 250).
 """
 from __future__ import annotations
 
@@ -122,14 +123,20 @@ class GraphPooling:
     MODES = {"mean": 0, "add": 1, "max": 2}
 
     def __init__(self, pooling_key, weights, device):
-        if pooling_key not in self.MODES:        # 'sort' needs a k and a Conv1d downstream in PyG; the reference never sets it
-            raise Exception("Unrecognized pooling key: " + pooling_key)
-        self.mode = self.MODES[pooling_key]
+        self.pooling_key = pooling_key           # like the reference, the key is only looked at in forward()
         self.w, self.b = _d(weights["lin.w"], device), _d(weights["lin.b"], device)
 
     @torch.no_grad()
     def forward(self, x, ptr):
-        return linear(segment_reduce(x, ptr, self.mode), self.w, self.b)
+        if self.pooling_key == "sort":
+            # model/gnn.py:135-136 calls `global_sort_pool(x, batch)` WITHOUT its required `k` (PyG 2.0.4:
+            # global_sort_pool(x, batch, k) sorts each graph's nodes by their last channel, keeps / zero-pads to k nodes
+            # and returns [B, k * d] -- which `self.lin` (num_in wide) could not take either): the reference raises this
+            # TypeError the first time the branch runs, so does the drop-in.
+            raise TypeError("global_sort_pool() missing 1 required positional argument: 'k'")
+        if self.pooling_key not in self.MODES:
+            raise Exception("Unrecognized pooling key: " + self.pooling_key)
+        return linear(segment_reduce(x, ptr, self.MODES[self.pooling_key]), self.w, self.b)
 
 
 class AttentionPooling:

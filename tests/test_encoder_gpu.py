@@ -519,3 +519,62 @@ def test_cooperative_query_embedding_slices_equal_the_full_batch(cuda):
         assert torch.equal(torch.cat(parts), full)
     assert query_slice(1000, 3, 1) == (0, 1000)            # world does not divide nq: every rank embeds everything
     assert gather_query_embeddings(full, nq) is full       # single process: nothing to gather
+
+
+@pytest.mark.parametrize("shape", ["fused", "wide"])
+def test_use_id_embedding_concatenates_the_id_row_in_front_of_the_text_features(cuda, shape):
+    """use_id_embedding=True (model/model.py:264,288-289): embedding['product'] = concat(id_embedding(x), text features)
+    -- product rows d_id + d_in wide, query rows d_in wide, every lazy (-1, -1) weight shaped accordingly.  Against the
+    oracle run on the concatenated inputs: table mode (item_text_table stand-in), `.feat` mode (text features brought
+    by the batch -> sss_gather_concat_rows writes [id row | feat] in one pass), node outputs at the reference's widths,
+    and the input masks."""
+    if shape == "fused":
+        cfg = EncoderConfig(d_in=64, d_id=32, h=128, n_layers=2, d_out=128, n_items=700, n_query=33)
+    else:       # the deployed widths: 768-wide text features + a 32-wide id embedding, h = 800, D = 1600 (per-op kernels)
+        cfg = EncoderConfig(d_in=768, d_id=32, h=800, n_layers=3, d_out=1600, n_items=300, n_query=17)
+    w = init_weights(cfg, 61)
+    assert w["item_table"].shape[1] == cfg.d_id and w["gat_pq.0.lin_src"].shape[1] == cfg.d_p
+    assert w["gat_qp.0.lin_src"].shape[1] == cfg.d_in and w["pool.query_lin.w"].shape[1] == cfg.node_width_q
+    enc = SessionEncoder(cfg, w, cuda)
+    assert enc.fused_ok() == (shape == "fused")
+    acts = S.synthetic_actions(50 if shape == "fused" else 24, 61, cfg.n_items, cfg.n_query)
+    b = S.build_batch(acts)
+    ref, rn = gnn_ref.encoder_forward(b.to_torch("cpu"), w, cfg.n_layers, get_node=True, use_id_embedding=True)
+    scale = max(1.0, float(ref.abs().max()))
+    got, gn = enc(b.to(cuda), get_node=True)
+    assert (got.cpu() - ref).abs().max() < TOL * scale
+    assert gn["query"].shape[1] == cfg.node_width_q and gn["product"].shape[1] == cfg.node_width
+    for t in ("query", "product"):
+        assert (gn[t].cpu() - rn[t]).abs().max() < TOL * max(1.0, float(rn[t].abs().max())), t
+    got2 = enc(enc.prepare_actions(acts))                                # native graph build, table mode
+    assert (got2.cpu() - ref).abs().max() < TOL * scale
+    # the batch brings its own text features (what the out-of-scope text encoder would emit)
+    g = torch.Generator().manual_seed(62)
+    bt = b.to_torch("cpu")
+    bt["query"].feat = torch.randn((bt["query"].x.shape[0], cfg.d_in), generator=g)
+    bt["product"].feat = torch.randn((bt["product"].x.shape[0], cfg.d_in), generator=g)
+    qm = (torch.rand(bt["query"].x.shape[0], generator=g) > 0.3).float()
+    pm = (torch.rand(bt["product"].x.shape[0], generator=g) > 0.3).float()
+    ref_f = gnn_ref.encoder_forward(bt, w, cfg.n_layers, use_id_embedding=True, query_node_mask=qm, product_node_mask=pm)
+    w_nf = {k: v for k, v in w.items() if k != "item_text_table"}        # no stand-in table needed in this mode
+    enc_f = SessionEncoder(cfg, w_nf, cuda)
+    bd = b.to(cuda)
+    bd["query"].feat, bd["product"].feat = bt["query"].feat.to(cuda), bt["product"].feat.to(cuda)
+    got_f = enc_f(bd, query_node_mask=qm.to(cuda), product_node_mask=pm.to(cuda))
+    assert (got_f.cpu() - ref_f).abs().max() < TOL * max(1.0, float(ref_f.abs().max()))
+
+
+def test_gather_concat_rows_is_bit_exact(cuda):
+    """sss_gather_concat_rows: out[i] = [table[ids[i]] | feat[i] | zeros] -- a copy kernel, compared bit for bit."""
+    g = torch.Generator().manual_seed(63)
+    table, feat = torch.randn((40, 32), generator=g), torch.randn((77, 72), generator=g)     # feat rows strided (72 > 64)
+    ids = torch.randint(0, 40, (77,), generator=g)
+    out = torch.full((77, 140), 9.0, device=cuda)
+    td, fd, idd = table.to(cuda), feat.to(cuda), ids.to(cuda)
+    rc = _lib.lib().sss_gather_concat_rows(td.data_ptr(), idd.data_ptr(), 32, fd.data_ptr(), 72, 64, 8, 77, out.data_ptr(), 140, _st(cuda))
+    _lib.check(rc, "sss_gather_concat_rows")
+    ref = torch.cat([table[ids], feat[:, :64], torch.zeros(77, 8), torch.full((77, 36), 9.0)], dim=1)
+    assert torch.equal(out.cpu(), ref)
+    rc = _lib.lib().sss_gather_concat_rows(0, 0, 0, fd.data_ptr(), 72, 64, 32, 77, out.data_ptr(), 140, _st(cuda))       # query rows: [feat | zeros]
+    _lib.check(rc, "sss_gather_concat_rows")
+    assert torch.equal(out.cpu()[:, :96], torch.cat([feat[:, :64], torch.zeros(77, 32)], dim=1))

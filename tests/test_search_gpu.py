@@ -224,6 +224,79 @@ def test_long_rows_bf16_index_and_id_offset(cuda):
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
 
 
+def test_long_rows_widest_rows_take_the_smaller_capacity(cuda):
+    """Rows beyond 10240 bytes (f32 d > 2560, bf16 d > 5120) up to the advertised 16384: k_select_all's LDS holds only
+    half the candidate capacity next to such a row -- the search must still be the long-row scan and exact, including a
+    group of tied rows larger than the smaller capacity (-> status 1 -> exhaustive kernels)."""
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(83)
+    q, c = _unit(rng, 9, 4096), _unit(rng, 9000, 4096)
+    c[4000:4030] = c[17]                                    # duplicates: exact ties inside the kept set
+    idx = _index(c, cuda)
+    D, I = idx.search(q, 100)
+    Dr, Ir = sr.search_exact(q, c, 100)
+    assert idx.last_scan == "long" and np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    c3 = np.tile(_unit(rng, 1, 4096), (5000, 1))            # 5000 identical rows > the 4096 kept for rows this wide
+    idx = _index(c3, cuda)
+    D, I = idx.search(q[:2], 10)
+    assert idx.last_fallback_queries == 2 and np.array_equal(I, np.tile(np.arange(10), (2, 1)))
+    qb, cb = _bf16_round(_unit(rng, 5, 8192)), _bf16_round(_unit(rng, 3000, 8192))
+    idx = FlatIndex(8192, "ip", cuda, dtype="bf16")
+    idx.add(cb)
+    D, I = idx.search(qb, 50)
+    Dr, Ir = sr.search_exact(qb, cb, 50)
+    assert idx.last_scan == "long" and np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    with pytest.raises(Exception):                          # k beyond what the status-1 fallback resolves: no long path, exhaustive limit
+        _index(c[:3000], cuda).search_fused(torch.from_numpy(q).to(cuda), 2000)
+
+
+def test_search_device_chunks_large_query_batches(cuda, monkeypatch):
+    """`index.search` takes the whole test set at once in the reference (test_amazon_filterd.py:578); the workspace is
+    per query, so search_device walks large batches in chunks -- same results, counters summed over the chunks."""
+    from sessionsimilaritysearch_amd import index as ix
+    rng = np.random.default_rng(84)
+    base = _unit(rng, 40, 128)
+    c = np.ascontiguousarray(np.repeat(base, 30, axis=0)[rng.permutation(1200)])     # 29 exact duplicates of every row
+    q = _unit(rng, 150, 128)
+    idx = _index(c, cuda)
+    D0, I0 = idx.search(q, 10)
+    r0 = idx.last_rescan_queries
+    monkeypatch.setattr(ix, "SEARCH_CHUNK", 64)
+    monkeypatch.setattr(ix, "SEARCH_CHUNK_LONG", 32)
+    D1, I1 = idx.search(q, 10)
+    assert np.array_equal(D0, D1) and np.array_equal(I0, I1) and idx.last_rescan_queries == r0 and r0 > 0
+    Dr, Ir = sr.search_exact(q, c, 10)
+    assert np.array_equal(I1, Ir) and np.array_equal(D1, Dr)
+    ql, cl = _unit(rng, 70, 320), _unit(rng, 4000, 320)
+    idl = _index(cl, cuda)
+    Dl, Il = idl.search(ql, 20)
+    Drl, Irl = sr.search_exact(ql, cl, 20)
+    assert idl.last_scan == "long" and np.array_equal(Il, Irl) and np.array_equal(Dl, Drl)
+
+
+def test_auto_scan_escalation_survives_streaming_adds(cuda):
+    """scan="auto" bookkeeping: an escalation earned on a corpus is kept across small add() calls (it was dropped on
+    every add), dropped once the corpus has doubled; the clean-search counter counts CONSECUTIVE clean searches."""
+    from sessionsimilaritysearch_amd.index import FlatIndex
+    rng = np.random.default_rng(85)
+    idx = FlatIndex(128, "ip", cuda)
+    idx.add(_unit(rng, 4000, 128))
+    idx.last_scan = "f16"
+    idx._note_fallbacks(10, 1024, 200)                      # 20 % of a batch unproven: class 0 moves up one scan
+    assert idx._auto_level.get(0) == 1
+    idx.add(_unit(rng, 100, 128))
+    assert idx._auto_level.get(0) == 1                      # a streaming add keeps it
+    idx._auto_clean.pop(("probe", 0), None)
+    idx.last_scan = "split"
+    for _ in range(5):
+        idx._note_fallbacks(10, 1024, 0)
+    assert idx._auto_clean[0] == 5
+    idx._note_fallbacks(10, 1024, 1)                        # one unproven query: not clean, the count restarts
+    assert idx._auto_clean[0] == 0
+    idx.add(_unit(rng, 5000, 128))                          # more than doubled since the escalation: a different corpus
+    assert idx._auto_level == {}
+
+
 def test_l2_metric(cuda):
     rng = np.random.default_rng(9)
     q = rng.standard_normal((10, 128)).astype(np.float32)
@@ -247,7 +320,7 @@ def test_exhaustive_path_on_long_rows_l2_ordered_and_tied(cuda):
     D, I = idx.search(q, 10)
     Dr, Ir = sr.build_index(c, "l2").search(q, 10)
     assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
-    # ascending similarity to query 0 (ip, d = 1600: no fused shape -> exhaustive for every query)
+    # ascending similarity to query 0 (ip, d = 1600: the long-row scan; the mass-tie query goes on to the exhaustive kernels)
     q2 = _unit(rng, 3, 1600)
     c2 = _unit(rng, 270000, 1600)
     c2 = np.ascontiguousarray(c2[np.argsort(c2 @ q2[0])])

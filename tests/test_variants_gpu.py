@@ -57,8 +57,12 @@ def test_graph_attention_srgnn_pooling_match_oracle(cuda):
         ref = vr.graph_pooling(x, batch, B, key, lin)
         got = GraphPooling(key, lin, cuda).forward(xd, ptr).cpu()
         assert (got - ref).abs().max() < TOL * max(1.0, float(ref.abs().max())), key
-    with pytest.raises(Exception):
-        GraphPooling("sort", lin, cuda)
+    # error behaviour as upstream (model/gnn.py:128-140): the key is looked at in forward(); 'sort' calls
+    # global_sort_pool without its required k -> TypeError; anything else -> Exception('Unrecognized pooling key: ...')
+    with pytest.raises(TypeError, match="missing 1 required positional argument: 'k'"):
+        GraphPooling("sort", lin, cuda).forward(xd, ptr)
+    with pytest.raises(Exception, match="Unrecognized pooling key: median"):
+        GraphPooling("median", lin, cuda).forward(xd, ptr)
     ref = vr.attention_pooling(x, batch, B, lin)
     got = AttentionPooling(lin, cuda).forward(xd, ptr).cpu()
     assert (got - ref).abs().max() < 2 * TOL * max(1.0, float(ref.abs().max()))
@@ -143,3 +147,55 @@ def test_binarize_head_eval_matches_oracle_and_feeds_the_binary_index(cuda, shap
     D, I = idx.search(packed[:100], 10)
     Dr, Ir = sr.hamming_search(ref_bits[:100], ref_bits[100:], 10)
     assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr)
+
+
+def test_conv_and_pool_variants_at_the_reference_widths(cuda):
+    """The scripts that use these variants run them at gnn_nhid = gnn_nout = 800 (config.py:15-16, model/gnn.py:83-181)
+    on 768-wide node features: HeteroSAGE 768 -> 800 -> 800 -> 800, GraphPooling / AttentionPooling / SRGNN_Pooling on
+    800-wide rows (gnn_pooling_out = 400).  Rows wider than 256 floats take the column-chunked kernels."""
+    from sessionsimilaritysearch_amd.variants import AttentionPooling, GraphPooling, HeteroSAGE, SRGNNPooling
+    b, pb = _batch(cuda, 60, 74)
+    g = torch.Generator().manual_seed(74)
+    d, h, out = 768, 800, 400
+    w = {}
+    for l in range(3):
+        din = d if l == 0 else h
+        for e in ("qp", "pq", "pp"):
+            w[f"sage.{l}.{e}.lin_l.w"] = _rand(g, h, din, scale=1.0 / np.sqrt(din))
+            w[f"sage.{l}.{e}.lin_l.b"] = _rand(g, h, scale=0.1)
+            w[f"sage.{l}.{e}.lin_r.w"] = _rand(g, h, din, scale=1.0 / np.sqrt(din))
+    xq, xp = torch.randn((pb.Nq, d), generator=g), torch.randn((pb.Np, d), generator=g)
+    ref = vr.hetero_sage(xq, xp, b.edge_index_dict, w)
+    got = HeteroSAGE(w, 3, cuda).forward(xq.to(cuda), xp.to(cuda), pb.csr_qp[:2], pb.csr_pq[:2], pb.csr_pp[:2])
+    for t in ("query", "product"):
+        assert got[t].shape[1] == h
+        assert (got[t].cpu() - ref[t]).abs().max() < TOL * max(1.0, float(ref[t].abs().max())), t
+    x = ref["product"]                                                  # 800-wide rows, as the pooling gets them upstream
+    xd, batch, B, ptr = x.to(cuda), b["product"].batch, b.num_graphs, pb.p_ptr
+    lin = {"lin.w": _rand(g, out, h, scale=1.0 / np.sqrt(h)), "lin.b": _rand(g, out, scale=0.1)}
+    for key in ("mean", "add", "max"):
+        r = vr.graph_pooling(x, batch, B, key, lin)
+        o = GraphPooling(key, lin, cuda).forward(xd, ptr).cpu()
+        assert (o - r).abs().max() < TOL * max(1.0, float(r.abs().max())), key
+    r = vr.attention_pooling(x, batch, B, lin)
+    o = AttentionPooling(lin, cuda).forward(xd, ptr).cpu()
+    assert (o - r).abs().max() < 2 * TOL * max(1.0, float(r.abs().max()))
+    sc = 1.0 / np.sqrt(h)
+    ws = {"lin1.w": _rand(g, h, h, scale=sc), "lin1.b": _rand(g, h, scale=0.1), "lin2.w": _rand(g, h, h, scale=sc),
+          "lin2.b": _rand(g, h, scale=0.1), "lin3.w": _rand(g, 1, h, scale=sc), "lin4.w": _rand(g, out, 2 * h, scale=sc),
+          "lin4.b": _rand(g, out, scale=0.1)}
+    mask = torch.zeros(pb.Np)
+    mask[(pb.p_ptr[1:].cpu().long() - 1)] = 1.0
+    r = vr.srgnn_pooling(x, batch, B, mask, ws)
+    o = SRGNNPooling(ws, cuda).forward(xd, ptr, mask).cpu()
+    assert (o - r).abs().max() < TOL * max(1.0, float(r.abs().max()))
+    # the widest rows the kernels take (2048) and a ragged width that leaves the last column chunk partly empty (1600)
+    for dd in (1600, 2048):
+        xw = torch.randn((pb.Np, dd), generator=g)
+        lw = {"lin.w": _rand(g, 32, dd, scale=1.0 / np.sqrt(dd)), "lin.b": _rand(g, 32, scale=0.1)}
+        r = vr.attention_pooling(xw, batch, B, lw)
+        o = AttentionPooling(lw, cuda).forward(xw.to(cuda), ptr).cpu()
+        assert (o - r).abs().max() < 2 * TOL * max(1.0, float(r.abs().max())), dd
+        r = vr.graph_pooling(xw, batch, B, "max", lw)
+        o = GraphPooling("max", lw, cuda).forward(xw.to(cuda), ptr).cpu()
+        assert (o - r).abs().max() < TOL * max(1.0, float(r.abs().max())), dd
