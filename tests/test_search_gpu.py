@@ -822,7 +822,9 @@ def test_auto_scan_steps_back_down_after_clean_searches(cuda):
         assert idx2.scan_for(10) == "split"
         idx2.search_device(far, 10)
     assert idx2.scan_for(10) == "f16"
-    idx.add(c[:10])                                         # a changed corpus starts from the default again
+    idx.add(c[:10])                                         # a streaming add keeps what the searches learned ...
+    assert idx.scan_for(10) == "split"
+    idx.add(_unit(rng, 61000, 128))                         # ... a corpus that has doubled since starts from the default again
     assert idx.scan_for(10) == "f16"
 
 
