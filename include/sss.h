@@ -181,6 +181,12 @@ int sss_topk_merge(const float* D_in, int64_t d_shard_stride, const int64_t* I_i
  * since the last read (state is per device: the calling thread's current device; at most 512
  * launches between reads). */
 int sss_profile_enable(int on);
+/* Diagnostic counter of the fused scans (csrc/scan.hip): the number of waves, since the last reset, whose bounded wait
+ * for the shared admission threshold at the end of the first warm-up tile ran out -- the workgroups of a launch were not
+ * co-resident (another stream's kernels held CUs).  Results stay exact (the affected queries lose their proof and go
+ * through the threshold rung), but the search is several times slower: a value other than 0 explains such a cliff.
+ * Synchronises the current device; reset != 0 zeroes the counter.  Returns the count, or a negative code. */
+int sss_scan_boot_expired(int reset);
 int sss_profile_read(double* total_ms, int* launches);
 
 /* ---- (i) encoder pieces.  NodeAsinEmbedding.forward -- model/NodeEmbedding.py:137-138:

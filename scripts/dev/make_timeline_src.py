@@ -22,7 +22,12 @@ src = sub1(src, "    constexpr int H = TR / 64;", "    TL(0); TL(1);\n    conste
 src = sub1(src, "    if (ntiles > 0) stage(0, tile_lo);\n", "    TL(2);\n    if (ntiles > 0) stage(0, tile_lo);\n")
 src = sub1(src, "    __syncthreads();\n\n    // The scan advances in 64-row steps", "    __syncthreads();\n    TL(3); TL(9);\n\n    // The scan advances in 64-row steps")
 src = sub1(src, "            set_tau(m);\n        }\n    };", "            set_tau(m);\n            TL(8);\n        }\n        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 101) && i < 96) g_tiles[(blockIdx.x ? 96 : 0) + i] = __builtin_amdgcn_s_memtime();\n    };")
-src = sub1(src, "    int t = 0;\n    while (t < T) {", "    int t = 0;\n    int n_rare = 0;\n    unsigned long long rare_cyc = 0;\n    while (t < T) {")
+src = sub1(src, "    int t = 0;\n    if constexpr (AP || THR) {", "    int t = 0;\n    int n_rare = 0;\n    unsigned long long rare_cyc = 0;\n    if constexpr (AP || THR) {")
+# the list-free forms' nested loop: rare-path entries and cycles
+src = sub1(src, "                if (live && __builtin_amdgcn_ballot_w64(m > thr) != 0) {\n",
+    "                if (live && __builtin_amdgcn_ballot_w64(m > thr) != 0) {\n                    ++n_rare;\n                    const unsigned long long rcn0 = __builtin_amdgcn_s_memtime();\n")
+src = sub1(src, "                        append_block(acc1, row0 + 32 + 4 * h);\n                    }\n",
+    "                        append_block(acc1, row0 + 32 + 4 * h);\n                    }\n                    rare_cyc += __builtin_amdgcn_s_memtime() - rcn0;\n")
 src = sub1(src, "        if (!rare) break;\n", "        if (!rare) break;\n        ++n_rare;\n        const unsigned long long rc0 = __builtin_amdgcn_s_memtime();\n")
 src = sub1(src, "        if (!defer && (unsigned)t % (unsigned)H == H - 1) tile_end((int)((unsigned)t / (unsigned)H));    // (rare implies t >= t_live)\n",
     "        rare_cyc += __builtin_amdgcn_s_memtime() - rc0;   // (NB: hipcc may hoist the next step's MFMAs above this stamp when no tile ends here)\n        if (!defer && (unsigned)t % (unsigned)H == H - 1) tile_end((int)((unsigned)t / (unsigned)H));\n")
@@ -48,5 +53,21 @@ src = sub1(src, "extern \"C\" int sss_debug_tiles(", "extern \"C\" int sss_debug
 # rare_cyc must be declared before tile_end: hoist
 src = sub1(src, "    int n_rare = 0;\n    unsigned long long rare_cyc = 0;\n", "    int n_rare = 0;\n")
 src = sub1(src, "    auto tile_end = [&](int i) {", "    unsigned long long rare_cyc = 0;\n    auto tile_end = [&](int i) {")
+# tile_top duration of wave 0 (workgroup 0), per tile: g_w[288 + i]; mfma_sub + score_tree durations summed per tile: g_w[384 + i]
+src = sub1(src, "    auto tile_top = [&](int i) {                // threshold refresh at the start of tile iteration i > 0\n",
+    "    auto tile_top_impl = [&](int i) {\n")
+src = sub1(src, "    auto tile_end = [&](int i) {",
+    "    auto tile_top = [&](int i) {\n        const unsigned long long tt0 = __builtin_amdgcn_s_memtime();\n        tile_top_impl(i);\n"
+    "        if (threadIdx.x == 0 && blockIdx.x == 0 && i < 96) g_w[288 + i] = __builtin_amdgcn_s_memtime() - tt0;\n    };\n    auto tile_end = [&](int i) {")
+assert src.count("        mfma_sub(i & 1, sub, next_tile);\n") == 2          # the split loop's and the nested loop's
+src = src.replace("        mfma_sub(i & 1, sub, next_tile);\n",
+    "        const unsigned long long mm0 = __builtin_amdgcn_s_memtime();\n        mfma_sub(i & 1, sub, next_tile);\n"
+    "        if (threadIdx.x == 0 && blockIdx.x == 0 && i < 96) g_w[384 + i] += __builtin_amdgcn_s_memtime() - mm0;\n")
+src = sub1(src, "            if (i > nb && i <= ntiles) publish(cls_live);\n            tau_fetch();                        // lands under this tile's MFMAs\n",
+    "            const unsigned long long pp0 = __builtin_amdgcn_s_memtime();\n            if (i > nb && i <= ntiles) publish(cls_live);\n"
+    "            const unsigned long long pp1 = __builtin_amdgcn_s_memtime();\n            tau_fetch();\n"
+    "            if (threadIdx.x == 0 && blockIdx.x == 0 && i < 96) { g_w[480 + i] = pp1 - pp0; g_w[576 + i] = __builtin_amdgcn_s_memtime() - pp1; }\n")
+src = src.replace("__device__ unsigned long long g_w[288];", "__device__ unsigned long long g_w[672];")
+src = src.replace("HIP_SYMBOL(sss::g_w), 288 * 8)", "HIP_SYMBOL(sss::g_w), 672 * 8)")
 open(os.path.join(root, "sessionsimilaritysearch_amd/csrc/scan_tl.hip"), "w").write(src)
 print("wrote csrc/scan_tl.hip")

@@ -45,6 +45,14 @@ print(json.dumps(dict(rc=rc, nq=nq, n=n, d=d, k=k, scan=scan,
     tail_cyc_med=float(np.median(t[:, 4] - t[:, 3])),
     boot_done_cyc_med=float(np.median(a[:, 8] - t[:, 2])), loop_start_us_med=float(np.median((a[:, 9] - rt0.min()) / 100.0)), rare_cyc_med=float(np.median(a[:, 10])), rare_med=float(np.median(a[:, 6])), rare_max=int(a[:, 6].max()))))
 
+live = dur_us > 1.0
+G_ = (nq + 255) // 256
+bid = np.arange(nwg)
+print("WG durations (us) of the live workgroups: pct 5/25/50/75/95/100 =", [round(float(np.percentile(dur_us[live], p)), 1) for p in (5, 25, 50, 75, 95, 100)])
+print("by XCD (bid & 7): mean / max", [(round(float(dur_us[live & ((bid & 7) == x)].mean()), 1), round(float(dur_us[live & ((bid & 7) == x)].max()), 1)) for x in range(8)])
+print("by query group:   mean / max", [(round(float(dur_us[live & (((bid >> 3) % G_) == g)].mean()), 1), round(float(dur_us[live & (((bid >> 3) % G_) == g)].max()), 1)) for g in range(G_)])
+order = np.argsort(-dur_us)[:12]
+print("slowest workgroups (bid, us, rare entries):", [(int(b), round(float(dur_us[b]), 1), int(a[b, 6])) for b in order])
 tb = (ctypes.c_ulonglong * 192)()
 L.sss_debug_tiles.argtypes = [ctypes.c_void_p]
 L.sss_debug_tiles(tb)
@@ -53,7 +61,7 @@ for o in (0, 96):
     v = tt[o:o + 96]; v = v[v > 0]
     print("tile-end deltas (cycles) wg", 0 if o == 0 else 101, ":", (v[0] - a[0 if o == 0 else 101, 3]), list(np.diff(v))[:70])
 
-wb = (ctypes.c_ulonglong * 288)()
+wb = (ctypes.c_ulonglong * 672)()
 L.sss_debug_w.argtypes = [ctypes.c_void_p]
 L.sss_debug_w(wb)
 w = np.array(wb, dtype=np.uint64).astype(np.int64)
@@ -61,3 +69,7 @@ nt = int((tt[:96] > 0).sum())
 print("wg 0 wave 0 per tile: vmcnt wait", list(w[:nt])[:40])
 print("wg 0 wave 0 per tile: barrier wait", list(w[96:96 + nt])[:40])
 print("wg 0 wave 0 per tile: rare cycles", list(np.diff(np.concatenate([[0], w[192:192 + nt]])))[:40])
+print("wg 0 wave 0 per tile: tile_top cycles", [int(v) for v in w[288:288 + nt]][:40])
+print("wg 0 wave 0 per tile: publish cycles", [int(v) for v in w[480:480 + nt]][:40])
+print("wg 0 wave 0 per tile: tau_fetch cycles", [int(v) for v in w[576:576 + nt]][:40])
+print("wg 0 wave 0 per tile: mfma_sub cycles", [int(v) for v in w[384:384 + nt]][:40])

@@ -4,7 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sessionsimilaritysearch_amd.index import FlatIndex, normalize_
 
-PEAK = {"f32": 157.3, "bf16": 2500.0}      # MI355X_MICROARCH.md dense peaks, TFLOP/s
+# MI355X_MICROARCH.md dense peaks, TFLOP/s, of the pipe the scan that RAN issues on (a float32 index scanned through
+# its f16 / split / long image runs on the 16-bit MFMA: the split scan spends three passes per pair-element)
+PEAK = {"f32": 157.3, "native": 2500.0, "f16": 2500.0, "long": 2500.0, "split": 2500.0 / 3}
 
 def run(nq, n, d, k, dtype="f32", iters=5):
     dev = torch.device("cuda", 0)
@@ -29,7 +31,7 @@ def run(nq, n, d, k, dtype="f32", iters=5):
     ms = e0.elapsed_time(e1) / iters
     tf = 2.0 * nq * n * d / (ms * 1e-3) / 1e12
     bad = int(out[2].sum().item())
-    print(json.dumps(dict(nq=nq, n=n, d=d, k=k, dtype=dtype, scan=idx.last_scan, ms=round(ms, 4), tflops=round(tf, 2), frac=round(tf / PEAK[dtype], 4),
+    print(json.dumps(dict(nq=nq, n=n, d=d, k=k, dtype=dtype, scan=idx.last_scan, ms=round(ms, 4), tflops=round(tf, 2), peak=round(PEAK[idx.last_scan], 1), frac=round(tf / PEAK[idx.last_scan], 4),
                           qps=round(nq / (ms * 1e-3)), unproven=bad)), flush=True)
 
 if __name__ == "__main__":

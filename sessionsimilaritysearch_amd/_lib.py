@@ -54,6 +54,7 @@ _SIGNATURES = {
                                           c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "sss_topk_merge": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_void_p,
                                c_void_p]),
+    "sss_scan_boot_expired": (c_int, [c_int]),
     "sss_profile_enable": (c_int, [c_int]),
     "sss_profile_read": (c_int, [c_void_p, c_void_p]),
     "sss_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),

@@ -48,6 +48,7 @@ int ip_topk_threshold(const void*, const int*, long, const void*, int, const voi
 int abs_max(const float*, long, float*, hipStream_t);
 int scale_f16(const float*, long, int, unsigned short*, hipStream_t);
 int topk_merge(const float*, long, const long*, long, int, long, int, float*, long*, hipStream_t);
+int scan_boot_expired(int);
 int profile_enable(int);
 int profile_read(double*, int*);
 size_t ip_topk_exhaustive_workspace_bytes(long nsel, long n);
@@ -194,6 +195,7 @@ int sss_topk_merge(const float* D_in, int64_t d_shard_stride, const int64_t* I_i
     return sss::topk_merge(D_in, d_shard_stride, reinterpret_cast<const long*>(I_in), i_shard_stride, shards, nq,
                            k, D_out, reinterpret_cast<long*>(I_out), ST(stream));
 }
+int sss_scan_boot_expired(int reset) { return sss::scan_boot_expired(reset); }
 int sss_profile_enable(int on) { return sss::profile_enable(on); }
 int sss_profile_read(double* total_ms, int* launches) { return sss::profile_read(total_ms, launches); }
 int sss_gather_rows(const float* table, const int64_t* ids, int64_t n, int d, float* out, int64_t ld_out,

@@ -92,6 +92,7 @@ static int ip_topk_impl(const void* q, long nq, const void* c_scan, int scan_dty
     a.Q = q; a.C = c_scan; a.nq = (int)nq; a.n = (int)n;
     a.tiles_per_split = p.tiles_per_split; a.total_tiles = p.total_tiles;
     a.S = p.S; a.G = p.G; a.J = p.J; a.Ju = p.Ju; a.cert = p.cert; a.boot = p.boot; a.append = p.append; a.cap = p.cap;
+    a.tau_skip = p.tau_skip;
     unsigned* sw = reinterpret_cast<unsigned*>(state);
     a.slots = sw;
     a.cnt = sw + state_off_cnt(nq);
@@ -106,7 +107,7 @@ static int ip_topk_impl(const void* q, long nq, const void* c_scan, int scan_dty
 
     SelectArgs s;
     s.Q = q; s.C = c_exact; s.nq = (int)nq; s.d = d; s.dtype = exact_dtype; s.scan_dtype = scan_dtype; s.corpus_shift = corpus_shift; s.corpus_resid = corpus_resid;
-    s.k = k; s.K2 = p.K2; s.J = p.J; s.cap = p.cap;
+    s.k = k; s.K2 = p.K2; s.J = p.J; s.cap = p.cap; s.tau_skip = p.tau_skip;
     s.cand = a.cand; s.slots = a.slots; s.cnt = a.cnt; s.maxlast = a.maxlast;
     s.id_offset = id_offset; s.corpus_max_norm = corpus_max_norm;
     s.D_out = D_out; s.I_out = I_out; s.status = status; s.unproven_count = unproven_count;

@@ -34,6 +34,10 @@ __host__ __device__ inline int f16_shift(float amax) {
 constexpr int KP = 16;          // per-lane candidate list length (register resident)
 constexpr int WG_QUERIES = 256; // queries per scan workgroup (8 waves x 32)
 constexpr int MAX_SLOTS = 128;  // admission-threshold slots per query (J <= MAX_SLOTS)
+// A query's slot words start SLOT_STRIDE words apart whatever J is: the 1024 lines of a 1024-query batch then spread
+// over 512 KB of address space -- and with it over the memory channels -- instead of sitting in 64 contiguous KB that
+// every workgroup of the launch polls, fetches and hits with agent-scope atomics at the same moment (the bootstrap).
+constexpr int SLOT_STRIDE = MAX_SLOTS;
 constexpr unsigned ORD_NEG_INF = 0x007FFFFFu;   // f2ord(-inf); slot value 0 = "never written"
 
 static inline int elem_bytes(int dtype) { return (dtype == DT_BF16 || dtype == DT_F16) ? 2 : 4; }
@@ -41,7 +45,7 @@ static inline int elem_bytes(int dtype) { return (dtype == DT_BF16 || dtype == D
 // STATE words (caller-owned, zero before the first call; every call leaves them zero: the select
 // kernel, their last reader, clears what the call used -- no per-call memset launch).  Because the
 // whole buffer is zero between calls, each call may lay it out as it likes:
-//   slots   u32 [nq][J]   admission-threshold slots (J = 16: 64 contiguous bytes per query)
+//   slots   u32 [nq][SLOT_STRIDE]   admission-threshold slots: the first J words of a query's 512 bytes (J = 16: one 64-byte line)
 //   cnt     u32 [nq]      candidates written per query        (at word nq * MAX_SLOTS)
 //   maxlast u64 [nq]      largest tail key over FULL lists    (8-byte aligned, after cnt)
 static inline size_t state_off_cnt(long nq) { return (size_t)nq * MAX_SLOTS; }                       // in words
@@ -50,7 +54,8 @@ static inline size_t state_words(long nq) { return state_off_maxlast(nq) + 2 * (
 
 // Per-search plan (host).  Workspace: cand u64 [nq][cap] compacted candidate keys, cap = L * KP.
 struct ScanPlan {
-    int G, S, L, K2, J, Ju, cert, boot, append, tile_rows;      // J slots per query, Ju <= J distinct classes (J == 16: the rest mirror them)
+    int G, S, L, K2, J, Ju, cert, boot, append, tile_rows;      // J slots per query = Ju classes; boot: the first tile of a split is scanned twice (max-only first)
+    int tau_skip;                                               // cert == 1: the threshold is the (tau_skip + 1)-th smallest slot (16 - K2)
     int total_tiles, tiles_per_split, cap;
     size_t total_bytes;
 };
@@ -61,6 +66,7 @@ struct ScanArgs {
     const void* Q;
     const void* C;
     int nq, n, tiles_per_split, total_tiles, S, G, J, Ju, cert, boot, append, cap;
+    int tau_skip = 0;
     unsigned* slots;                // the three arrays live in the caller's state buffer
     unsigned* cnt;
     unsigned long long* maxlast;
@@ -72,11 +78,13 @@ struct ScanArgs {
 
 ScanPlan make_thr_plan(long nsel, long n, int d, int scan_dtype, int cap);
 int launch_scan(int dtype, int d, int tile_rows, const ScanArgs& a, hipStream_t st);
+int scan_boot_expired(int reset);
 
 struct SelectArgs {
     const void* Q;
     const void* C;
     int nq, d, dtype, k, K2, J, cap;
+    int tau_skip = 0;               // the scan's rank-selected threshold: (tau_skip + 1)-th smallest of the 16 slots
     int scan_dtype;                 // what produced the candidates (DT_F32 / DT_BF16 / DT_SPLIT / DT_F16): picks the error bound
     int corpus_shift;               // DT_F16: the corpus image is corpus * 2^corpus_shift (else 0)
     float corpus_resid;             // DT_F16: largest row norm of (image * 2^-corpus_shift - corpus)

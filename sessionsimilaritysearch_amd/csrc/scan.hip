@@ -31,10 +31,15 @@
 //     has seen (cert == 1) or the largest cert-th best of such a list (cert > 1).  Classes
 //     partition the corpus rows, so tau = min over slots is a score that at least J * cert >= K2
 //     distinct rows reach, and a row scoring below tau can never be among the best K2.  With
-//     cert == 1 the first tile of every split is scanned twice: once max-only to publish
-//     (bootstrap), and again at the end with the lists live, so no row is lost and the expensive
-//     "early phase" of a running top-k (every row beats an empty list) never happens.  Slots only
-//     ever hold scores of real rows and only grow, so a stale read merely admits extra candidates:
+//     cert == 1 (K2 <= 16) all 16 slots are distinct classes and tau is RANK-SELECTED: the K2-th largest
+//     class maximum (scan_dev.h: tau_select16) -- K2 distinct rows reach it as well, and it sits near the
+//     ~21st best row seen instead of the ~37th of "min over K2 classes".  The first tile of every split is
+//     scanned twice: once max-only to publish (bootstrap: publish, then a bounded wait for the other
+//     workgroups), and again at the end with the lists live, so no row is lost and the expensive "early
+//     phase" of a running top-k (every row beats an empty list) never happens.  (More than one max-only
+//     tile -- B tiles put B x as many rows behind the first live threshold -- was built and measured in
+//     round 4: candidates fall further, the time does not: the extra tiles cost what they save.)  Slots
+//     only ever hold scores of real rows and only grow, so a stale read merely admits extra candidates:
 //     speed, never correctness;
 //   * at the end each lane appends its real entries to the query's compact candidate array
 //     (one atomic add per lane) for k_select_* (select.hip);
@@ -58,6 +63,9 @@ namespace sss {
 // ip_topk.hip: ip_topk_threshold): the queries are the compact list A.qsel, every lane compares against
 // its query's FIXED threshold A.thr[] (scan domain) instead of a running list, and every row above it is
 // appended to the query's candidate array -- no lists, no shared threshold, no bootstrap.
+// waves whose bootstrap wait expired before the threshold existed (read + reset through scan_boot_expired)
+__device__ unsigned g_boot_expired;
+
 template <int RB, int TR, int DT, int NW, bool THR = false, bool AP = false>
 __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(const ScanArgs A) {
     constexpr int H = TR / 64;                        // 64-row sub-steps per tile
@@ -123,27 +131,34 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
     if (tile_hi > A.total_tiles) tile_hi = A.total_tiles;
     const int ntiles = tile_lo < tile_hi ? tile_hi - tile_lo : 0;
     const bool use_tau = !THR && J > 0;
+    // bootstrap: the first tile of the split is scanned max-only first (iteration 0) and again, live, at the end
+    // (iteration ntiles)
     const bool boot = use_tau && A.boot && ntiles > 0;
-    const int niter = ntiles + (boot ? 1 : 0);
-    // iteration -> tile: with the bootstrap the first tile is scanned at iteration 0 (max only)
-    // and again at the last iteration (lists live)
-    auto tile_of = [&](int i) { return (boot && i == ntiles) ? tile_lo : tile_lo + i; };
+    const int nb = boot ? 1 : 0;
+    const int niter = ntiles + nb;
+    auto tile_of = [&](int i) { return i < ntiles ? tile_lo + i : tile_lo; };
+    const int skip = A.tau_skip;                 // rank-selected threshold (cert == 1, J == 16): 16 - K2
 
-    unsigned cls_byte = 0;                       // byte offset of this lane's class inside its query's 64 B of slots
     bool slots_seen = false;                     // the LDS copy of the slots has been filled at least once
-    unsigned* my_slot = nullptr;
-    unsigned* my_mirror = nullptr;              // second slot of this class when fewer classes than slots (scan.h: Ju)
     const unsigned* my_half = nullptr;
+    unsigned cls_live = 0;                       // class of this lane's rows
+    // cert == 1: a class is a set of SPLITS (split & 15; both lanes of a query's (h = 0, 1) pair belong to it), so the
+    // pair publishes ONE value -- the better of its two lane maxima, by lane h = 0: half the agent-scope atomics (at the
+    // bootstrap 128 instead of 256 per query line, which all arrive within a microsecond and serialise at the line's
+    // memory channel).  cert > 1: a class per lane list, as the lists certify `cert` rows each.
+    const bool pair_pub = A.cert == 1;
     if (use_tau) {
-        const unsigned cls = (unsigned)(2 * split + h) % (unsigned)A.Ju;
-        cls_byte = cls * 4u;
-        my_slot = A.slots + (size_t)q_ld * J + cls;
-        if ((int)cls + A.Ju < J) my_mirror = my_slot + A.Ju;
-        my_half = A.slots + (size_t)q_ld * J + h * (J >> 1);
+        cls_live = pair_pub ? (unsigned)split & 15u : (unsigned)(2 * split + h) % (unsigned)A.Ju;
+        my_half = A.slots + (size_t)q_ld * SLOT_STRIDE + h * (J >> 1);
     }
-    // min over the query's J slots.  Synchronous form (bootstrap wait; J > 16): each lane of the
-    // (h = 0, 1) pair reads half, 8 slots a step, with agent-scope loads.
+    // Threshold word of the query from its J slots.  Synchronous form (bootstrap wait; J > 16): each lane of the
+    // (h = 0, 1) pair reads half with agent-scope loads.  J == 16 with a rank: the (skip + 1)-th smallest; else the min.
     auto tau_ord = [&]() -> unsigned {
+        if (J == 16 && skip > 0) {
+            unsigned v[8];
+            load8_sc1(my_half, v);
+            return tau_select16(v, skip, h);
+        }
         unsigned m = 0xFFFFFFFFu;
         for (int v = 0; v < (J >> 1); v += 8) m = min(m, min8_sc1(my_half + v));
         return min(m, (unsigned)__shfl_xor((int)m, 32));
@@ -154,11 +169,16 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
     // stall, no registers held.
     const unsigned tau_lds = (unsigned)(unsigned long)(lptr_c)smem + TAU_LDS + wave * 2048;
     auto tau_fetch = [&]() {
+        // (the lane offsets are recomputed from an OPAQUE copy of the lane id at every refresh: as loop invariants the
+        //  compiler kept them in registers for the whole scan -- at the append form's register limit, in scratch, with a
+        //  reload + vmcnt(0) in front of each of the two DMA instructions, which serialised them)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            int qi = g * WGQ + wave * 32 + 16 * j + (lane >> 2);
+            int qi = g * WGQ + wave * 32 + 16 * j + (ln >> 2);
             if (qi > nq - 1) qi = nq - 1;
-            const unsigned off = (unsigned)qi * 64u + (unsigned)(lane & 3) * 16u;
+            const unsigned off = (unsigned)qi * (unsigned)(SLOT_STRIDE * 4) + (unsigned)(ln & 3) * 16u;
             const unsigned dst = __builtin_amdgcn_readfirstlane(tau_lds + j * 1024);
             // (M0 is written without a save / restore: hipcc has no use of its own for M0 in this kernel -- no dynamic
             //  register indexing, no LDS-direct / GWS / sendmsg; every M0 reference in the ISA comes from these statements)
@@ -169,6 +189,10 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
     auto tau_read = [&]() -> unsigned {
         const u32x4* p = reinterpret_cast<const u32x4*>(smem + TAU_LDS + wave * 2048 + r * 64 + h * 32);
         const u32x4 a = p[0], b = p[1];
+        if (skip > 0) {
+            unsigned v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            return tau_select16(v, skip, h);
+        }
         const unsigned m = min(min(min(a.x, a.y), min(a.z, a.w)), min(min(b.x, b.y), min(b.z, b.w)));
         return min(m, (unsigned)__shfl_xor((int)m, 32));
     };
@@ -176,7 +200,7 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
         if (m > ORD_NEG_INF) tau = fmaxf(tau, ord2f(m - 1));     // the float just below the min slot
         thr = AP ? tau : fmaxf(ls[KP - 1], tau);
     };
-    auto publish = [&]() {
+    auto publish = [&](unsigned cls) {
         float val = rmax;
         bool ok = true;
         if (A.cert > 1) {
@@ -193,11 +217,15 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
         // are not class records.  The last fetched copy of the slots (LDS, J == 16) tells: without this filter the
         // early tiles, where every lane sets records all the time, spend most of their time waiting for some
         // hundred agent-scope atomics per query line to drain (vmcnt(0) at the end of the tile).
+        if (pair_pub) { val = fmaxf(val, __shfl_xor(val, 32)); ok = h == 0; }
         unsigned cur = 0u;
-        if (J == 16 && slots_seen) cur = *reinterpret_cast<const unsigned*>(smem + TAU_LDS + wave * 2048 + r * 64 + cls_byte);
-        if (ok && val > pub && val > tau && f2ord(val) > cur && q_glob < nq) {     // at or below tau it cannot raise the minimum
-            __hip_atomic_fetch_max(my_slot, f2ord(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (my_mirror) __hip_atomic_fetch_max(my_mirror, f2ord(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (J == 16 && slots_seen) cur = *reinterpret_cast<const unsigned*>(smem + TAU_LDS + wave * 2048 + r * 64 + cls * 4u);
+        if (ok && val > pub && val > tau && f2ord(val) > cur && q_glob < nq) {     // at or below tau it cannot raise the threshold
+            // (the slot address is rebuilt from an opaque copy of the query index: a 64-bit per-lane pointer kept across the
+            //  scan costs two registers the append form does not have -- it was spilled and reloaded here)
+            int qq = THR ? q_ld : q_glob;
+            asm volatile("" : "+v"(qq));
+            __hip_atomic_fetch_max(A.slots + ((size_t)(unsigned)qq * (unsigned)SLOT_STRIDE + cls), f2ord(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pub = val;
         }
     };
@@ -417,28 +445,37 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
     // ~70 v_mov per step on the hot path.)
     const int T = niter * H;
     long row0_of_step = 0;                      // first corpus row of the current step
-    // The threshold moves fast at first and then ever more slowly, and a stale one only admits extra
-    // candidates: the 16-bit scans (whose tiles take a few microseconds) refresh it every tile for the first
-    // 8 tiles and then every 512 rows -- measured 4 % on the f16 scan; the f32 scan (15 us per tile) keeps
-    // refreshing every tile.
-    constexpr int TAU_EVERY = DT == DT_F32 ? 1 : (TR >= 512 ? 1 : 512 / TR);
-    auto refresh_at = [&](int i) { return TAU_EVERY == 1 || i <= 8 || (i % TAU_EVERY) == 0; };
+    // The threshold moves fast at first and then ever more slowly, and a stale one only admits extra candidates.  A
+    // refresh is not cheap in a 16-bit scan: its two LDS-DMA instructions (and the publish's atomic) queue behind the
+    // tile traffic of the CU's memory pipe -- ~3 k cycles per wave, half a 128-row tile (per-tile stamps, DESIGN.md
+    // 5.1).  With tau near the R-th best of the i tiles' rows seen so far, ~R / i rows per query pass per tile-time and
+    // a threshold stale by D tiles admits ~R D / i^2 more: the cost of refreshing every D tiles, c_r / D + c_p D / i^2
+    // per tile, is least at D ~ i -- so the 16-bit scans refresh at i = 1, 2, 3, 4 and then at 2 and 3 times the powers
+    // of two (6, 8, 12, 16, 24, ...: 12 refreshes of a 61-tile split instead of 21, 18 of 610 instead of 158).  The
+    // f32 scan (15 us per tile) keeps refreshing every tile.
+    constexpr bool TAU_EVERY_TILE = DT == DT_F32 || TR >= 512;
+    auto refresh_at = [&](int i) {
+        if (TAU_EVERY_TILE || i <= 4) return true;
+        const int sh = 30 - __builtin_clz(i);              // i = (2 or 3) << sh  <=>  its low sh bits are zero
+        return (i & ((1 << sh) - 1)) == 0;
+    };
     auto tile_top = [&](int i) {                // threshold refresh at the start of tile iteration i > 0
         if (!use_tau || i == 0) return;
         if (J == 16) {
             if (!refresh_at(i)) return;
+            publish(cls_live);                  // (before the fetch: an atomic behind the two DMA instructions waits for them)
             tau_fetch();                        // lands under this tile's MFMAs
-        } else {
-            // J > 16 (k > 116): synchronous loads, rarely, staggered between the two waves of a
-            // SIMD (waves 4-7 one tile later) so the partner keeps the matrix pipe busy meanwhile.
-            const int ii = i - (wave >= 4 ? 1 : 0);        // (NW == 4: no SIMD partner, nothing to stagger)
-            if (ii >= 2 && (ii <= 8 || (ii & (ii - 1)) == 0 || (ii & 15) == 0)) set_tau(tau_ord());
+            return;
         }
-        publish();                              // completes under this tile's MFMAs
+        // J > 16 (k > 116): synchronous loads, rarely, staggered between the two waves of a
+        // SIMD (waves 4-7 one tile later) so the partner keeps the matrix pipe busy meanwhile.
+        const int ii = i - (wave >= 4 ? 1 : 0);        // (NW == 4: no SIMD partner, nothing to stagger)
+        if (ii >= 2 && (ii <= 8 || (ii & (ii - 1)) == 0 || (ii & 15) == 0)) set_tau(tau_ord());
+        publish(cls_live);                      // completes under this tile's MFMAs
     };
     auto tile_end = [&](int i) {
         const bool pre = boot && i == 0;
-        if (pre) publish();
+        if (pre) publish(cls_live);
         // this wave's share of the next tile landed (after the bootstrap tile: its own atomics did -- skipping this wait
         // there only moves it into the polling loop below, measured slower)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -456,6 +493,9 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
                 if (__builtin_amdgcn_ballot_w64(m == 0) == 0) break;
                 __builtin_amdgcn_s_sleep(16);
             }
+            // (debug counter, sss_scan_boot_expired: the wait ran out before K2 classes of every query had published --
+            //  the workgroups of the launch were not co-resident; correct all the same, but the append form then floods)
+            if (lane == 0 && __builtin_amdgcn_ballot_w64(m == 0 && q_glob < nq) != 0) atomicAdd(&g_boot_expired, 1u);
             set_tau(m);
         }
     };
@@ -486,7 +526,7 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
         rmax = mm;
         return vmax3(m, acc1[15], acc1[15]);
     };
-    const int t_live = boot ? H : 0;            // steps of the bootstrap tile: lane maximum only
+    const int t_live = nb * H;                  // steps of the bootstrap tile: lane maximum only
     // STAGGER (MI355X_MICROARCH.md, two waves per SIMD, item 9): the two waves of a SIMD run the same program and
     // leave every barrier together -- both into their MFMAs, then both into their max trees, the matrix pipe idle
     // meanwhile.  Waves 4-7 (the SIMD partners of waves 0-3) therefore take the end of a tile -- wait, threshold
@@ -496,6 +536,48 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
     // to +1 % (their partners drift apart by themselves), so those keep the plain order.
     const bool defer = SSS_STAGGER && NW == 8 && (DT == DT_SPLIT || DT == DT_BF16) && wave >= 4;
     int t = 0;
+    if constexpr (AP || THR) {
+        // The forms WITHOUT lane lists (append, threshold) have no list state to keep out of the hot loop, so theirs is the
+        // plain nest: tiles x (compile-time) sub-steps, the rare path an ordinary side branch.  What that buys is SCALAR
+        // instructions: a SIMD issues one scalar instruction per 4 cycles, and the split loop below spends ~90 per
+        // 64-row step on t / H, t % H, tile-of-iteration, 64-bit row arithmetic and the ragged-tile test -- with four
+        // waves per SIMD that is ~70 % of the scalar issue slots of a step, the append form's real limit (the matrix
+        // pipe is ~70 % busy, the two co-resident workgroups together finish in the same time however the SIMDs
+        // arbitrate between them: section 5.1).  Here the per-tile values are computed once per tile.
+        t = T;                                                  // (the split loop below is not entered)
+        for (int i = 0; i < niter; ++i) {
+            tile_top(i);
+            const int tile = tile_of(i);
+            const int next_tile = (i + 1 < niter && !(two_ahead && i == 0)) ? tile_of(i + 1) : -1;
+            const int row_base = tile * TR;
+            const bool ragged = row_base + TR > n;              // wave-uniform, last tile of the corpus only
+            const bool live = i >= nb;
+#pragma unroll
+            for (int sub = 0; sub < H; ++sub) {
+                mfma_sub(i & 1, sub, next_tile);
+                const int row0 = row_base + sub * 64;
+                if (ragged) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int rr = row0 + 4 * h + (j & 3) + 8 * (j >> 2);
+                        if (rr >= n) acc0[j] = -INFINITY;
+                        if (rr + 32 >= n) acc1[j] = -INFINITY;
+                    }
+                }
+                const float m = score_tree();
+                if (live && __builtin_amdgcn_ballot_w64(m > thr) != 0) {
+                    if constexpr (THR) {
+                        emit_block(acc0, row0 + 4 * h);
+                        emit_block(acc1, row0 + 32 + 4 * h);
+                    } else {
+                        append_block(acc0, row0 + 4 * h);
+                        append_block(acc1, row0 + 32 + 4 * h);
+                    }
+                }
+            }
+            tile_end(i);
+        }
+    }
     while (t < T) {
         bool rare = false;
         for (; t < T; ++t) {                    // ---- hot loop
@@ -541,6 +623,14 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
 }
 
 // ------------------------------------------------------------------------------ host side
+// Number of waves, since the last reset, whose bootstrap wait ran out (synchronises the device: a debugging / bench aid).
+int scan_boot_expired(int reset) {
+    unsigned v = 0, zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_boot_expired), sizeof(v)) != hipSuccess) { set_error("scan_boot_expired: read failed"); return SSS_EHIP; }
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_boot_expired), &zero, sizeof(zero)) != hipSuccess) { set_error("scan_boot_expired: reset failed"); return SSS_EHIP; }
+    return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
+}
+
 int current_device() {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -634,10 +724,11 @@ static ScanPlan make_plan_for(long nq, long n, int d, int k, int dtype, bool wan
     p.J = p.K2 <= 128 ? 16 : 64;
     p.cert = 1;
     while (p.J * p.cert < p.K2 && p.cert < KP) p.cert *= 2;
-    // K2 < 16: only Ju = K2 distinct classes; slots Ju .. 15 mirror classes 0 .. 15 - Ju (their publishers write both),
-    // so that "min over the 16 slots" -- what every reader computes -- IS the min over the Ju class maxima
-    p.Ju = (p.cert == 1 && p.K2 < p.J) ? p.K2 : p.J;
-    if (p.J * p.cert < p.K2 || 2 * active_splits < p.Ju) { p.J = 0; p.Ju = 0; }      // tiny corpus: no threshold
+    // cert == 1 (K2 <= 16): all 16 slots are distinct classes and the threshold is the K2-th largest class maximum
+    // (tau_skip = 16 - K2 words allowed below it; scan_dev.h: tau_select16)
+    p.Ju = p.J;
+    p.tau_skip = (p.cert == 1 && p.J == 16) ? 16 - p.K2 : 0;
+    if (p.J * p.cert < p.K2 || 2 * active_splits < p.Ju) { p.J = 0; p.Ju = 0; p.tau_skip = 0; }      // tiny corpus: no threshold
     p.boot = (p.J > 0 && p.cert == 1) ? 1 : 0;
     p.append = (want_append && p.boot) ? 1 : 0;
     if (want_append && !p.append) return p;               // (the caller falls back to the list plan)

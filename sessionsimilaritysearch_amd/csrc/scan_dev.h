@@ -44,6 +44,52 @@ __device__ __forceinline__ unsigned min8_sc1(const unsigned* p) {
     return min(m0, m1);
 }
 
+// Compare-exchange of two u32 (ascending).
+__device__ __forceinline__ void cx_u32(unsigned& a, unsigned& b) {
+    const unsigned lo = min(a, b), hi = max(a, b);
+    a = lo; b = hi;
+}
+
+// RANK-SELECTED THRESHOLD (cert == 1, 16 slots = 16 class maxima of one query).  Any word v that at least K2 of the
+// 16 slots reach is a valid threshold (K2 distinct rows, one per class, score at least v); the old rule, "min over K2
+// classes", sits near the ~37th best row seen for K2 = 12, the K2-th largest of 16 class maxima near the ~21st
+// (coupon-collector ranks 12 H12 vs 16 (H16 - H4)): 1.8x fewer rows pass.  The (h = 0, 1) lane pair of a query holds
+// 8 words each; with skip = 16 - K2 words allowed below the threshold, lane h takes its m_h-th smallest word,
+// m_0 + m_1 = skip + 2 (m_h = skip / 2 + 1, lane 0 one more when skip is odd), and the pair's minimum is returned:
+// at most m_0 - 1 + m_1 - 1 = skip words lie below it.  That is the exact (skip + 1)-th smallest when the skip words
+// below it split evenly over the halves and one or two ranks lower otherwise -- for one sorting network on 8 registers,
+// one cross-lane exchange and no data-dependent indexing (the exact merge of the two sorted halves cost 16 more
+// registers and spilled the append form's hot loop).  A word of 0 ("class never published") sorts first: the result
+// is 0 until enough classes of BOTH halves have published.  The select kernel, which runs once per query, takes the
+// exact rank (select.hip: final_tau_ord) -- any threshold the scan used lies at or below it.
+__device__ __forceinline__ unsigned tau_select16(unsigned (&v)[8], int skip, int h) {
+    // optimal 19-comparator sorting network for 8 inputs
+    cx_u32(v[0], v[1]); cx_u32(v[2], v[3]); cx_u32(v[4], v[5]); cx_u32(v[6], v[7]);
+    cx_u32(v[0], v[2]); cx_u32(v[1], v[3]); cx_u32(v[4], v[6]); cx_u32(v[5], v[7]);
+    cx_u32(v[1], v[2]); cx_u32(v[5], v[6]); cx_u32(v[0], v[4]); cx_u32(v[3], v[7]);
+    cx_u32(v[1], v[5]); cx_u32(v[2], v[6]);
+    cx_u32(v[1], v[4]); cx_u32(v[3], v[6]);
+    cx_u32(v[2], v[4]); cx_u32(v[3], v[5]);
+    cx_u32(v[3], v[4]);
+    const int m = (skip >> 1) + ((skip & 1) && h == 0 ? 1 : 0);       // 0-based index of this lane's word, <= 4 (skip <= 8)
+    unsigned mine = v[0];
+    mine = m >= 1 ? v[1] : mine;
+    mine = m >= 2 ? v[2] : mine;
+    mine = m >= 3 ? v[3] : mine;
+    mine = m >= 4 ? v[4] : mine;
+    return min(mine, (unsigned)__shfl_xor((int)mine, 32));
+}
+
+// The same two agent-scope loads, handing back the 8 words (rank-selected threshold).
+__device__ __forceinline__ void load8_sc1(const unsigned* p, unsigned (&v)[8]) {
+    u32x4 a, b;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
 // Resident queries of one 32-query MFMA B operand: lane (r, h) ends up with the 16-byte chunks of query row
 // q_ld it meets in the k-groups (qc[u]: k = 16u + 8h .. + 7 for the 16-bit types, chunk 2u + h for f32).
 // DT_SPLIT / DT_F16 take float32 queries and split / scale + round them here (scan.h).

@@ -181,12 +181,26 @@ __device__ __forceinline__ double err_bound(int d, int scan_dtype, double qnorm,
 
 // Hand the query's state words back zeroed (scan.h: the contract that replaces a per-call memset).
 __device__ __forceinline__ void clear_state(const SelectArgs& A, int q, int t, int nthreads) {
-    for (int j = t; j < A.J; j += nthreads) A.slots[(size_t)q * A.J + j] = 0u;
+    for (int j = t; j < A.J; j += nthreads) A.slots[(size_t)q * SLOT_STRIDE + j] = 0u;
     if (t == 0) { A.cnt[q] = 0u; A.maxlast[q] = 0ull; }
 }
 
-// min over the J threshold slots of query q as an ordered-uint (0: some class never published)
-__device__ __forceinline__ unsigned final_tau_ord(const unsigned* slots, int J, int lane) {
+// The scan's final threshold word of query q from its J slots (0: not enough classes ever published): the min, or --
+// rank-selected scans (cert == 1, J == 16: scan_dev.h tau_select16) -- the exact (skip + 1)-th smallest of the 16
+// (the scan's own, cheaper pick lies at or below it).
+// Called by a whole wave.
+__device__ __forceinline__ unsigned final_tau_ord(const unsigned* slots, int J, int lane, int skip) {
+    if (skip > 0 && J == 16) {
+        const unsigned mine = slots[lane & 15];
+        int rank = 0;                                             // values ordered by (word, slot index): ranks 0 .. 15
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const unsigned o = (unsigned)__shfl((int)mine, j);
+            rank += (o < mine || (o == mine && j < (lane & 15))) ? 1 : 0;
+        }
+        const unsigned long long own = __builtin_amdgcn_ballot_w64(lane < 16 && rank == skip);
+        return (unsigned)__builtin_amdgcn_readlane((int)mine, __builtin_ctzll(own));
+    }
     unsigned m = 0xFFFFFFFFu;
     for (int j = lane; j < J; j += 64) m = min(m, slots[j]);
 #pragma unroll
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
         Dq[j] = -3.4028234663852886e38f;
         Iq[j] = -1;
     }
-    const unsigned tau_o = A.J > 0 ? final_tau_ord(A.slots + (size_t)q * A.J, A.J, lane) : 0u;
+    const unsigned tau_o = A.J > 0 ? final_tau_ord(A.slots + (size_t)q * SLOT_STRIDE, A.J, lane, A.tau_skip) : 0u;
     const unsigned long long maxlast = A.maxlast[q];
     wave_sync();                                                  // every lane has read the state words
     clear_state(A, q, lane, 64);
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
         Iq[j] = -1;
     }
     if (tid < 64) {                                               // wave 0 alone touches the state from here on
-        const unsigned tau_o = A.J > 0 ? final_tau_ord(A.slots + (size_t)q * A.J, A.J, lane) : 0u;
+        const unsigned tau_o = A.J > 0 ? final_tau_ord(A.slots + (size_t)q * SLOT_STRIDE, A.J, lane, A.tau_skip) : 0u;
         const unsigned long long maxlast = A.maxlast[q];
         wave_sync();
         clear_state(A, q, lane, 64);
