@@ -23,6 +23,7 @@
 // Two to three passes, the last one dominant; no per-lane list, no shared threshold slots, no bootstrap.
 #include "scan.h"
 #include <cmath>
+#include <cstdlib>
 #include "scan_dev.h"
 
 namespace sss {
@@ -30,12 +31,20 @@ namespace sss {
 constexpr int LT_ROWS = 256;        // corpus rows per workgroup tile
 constexpr int LT_Q = 256;           // queries per workgroup (8 waves x 32)
 constexpr int LT_BK = 128;          // bytes of K per slab (64 16-bit elements = 4 MFMA k-groups)
-constexpr int LT_STAGE = (LT_ROWS + LT_Q) * LT_BK;     // 64 KB: one slab of both operands
+constexpr int LT_HALF = LT_ROWS * LT_BK;               // 32 KB: one slab of ONE operand (LT_ROWS == LT_Q)
+// LDS: the corpus slabs in a ring of THREE, the query slabs in a ring of two -- all 160 KB.  The corpus slab (streamed
+// from HBM: the long latency) is fetched two slabs ahead, the query slab (L2-resident) one: half the bytes that must
+// land within one slab's matrix time, and the far operand gets the deep look-ahead (counters, round 4: the waves were
+// parked 52 % of their cycles waiting for the single 64 KB slab in flight; L2 hit rate 71 %, fetch from HBM ~1.2x
+// algorithmic, no LDS stall or conflict -- the bound was the latency of a one-slab look-ahead, not a rate).
+constexpr int LT_LDS_BYTES = 5 * LT_HALF;
+static_assert(LT_ROWS == LT_Q, "the two operand slabs have one size");
 
 struct LongArgs {
     const void* Qimg;               // [nq][d] 16-bit queries (f16: scaled image, bf16: the queries themselves)
     const void* C;                  // [n][d] 16-bit rows (f16 image / bf16 rows)
     int nq, n, d, G, S;
+    int gpx;                        // query groups that share an XCD (block map below); divides G, G / gpx divides 8
     int dense;                      // sample level (many rows kept per lane and tile): aggregated appends
     int tile_count;                 // tiles this level scans: tile j of the level = corpus tile j * total_tiles / tile_count
     int total_tiles, tiles_per_split, cap;
@@ -59,8 +68,15 @@ __global__ __launch_bounds__(256) void k_query_f16(const float* __restrict__ q, 
     for (int kk = lane; kk < d; kk += 64) out[(size_t)i * d + kk] = (_Float16)ldexpf(row[kk], sh);
 }
 
+#ifndef SSS_LT_LOADERS
+#define SSS_LT_LOADERS 4
+#endif
+constexpr int LT_LOADERS = SSS_LT_LOADERS;             // loader waves per workgroup (one per SIMD), behind the 8 matrix waves
+constexpr int LT_NP = 32 / LT_LOADERS;                 // 1 KiB pieces of an operand slab per loader
+constexpr int LT_THREADS = (8 + LT_LOADERS) * 64;
+
 template <int DT>
-__global__ __launch_bounds__(512, 2) void k_scan_long(const LongArgs A) {
+__global__ __launch_bounds__(LT_THREADS, (LT_THREADS + 255) / 256) void k_scan_long(const LongArgs A) {
     static_assert(DT == DT_F16 || DT == DT_BF16, "16-bit rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nq = A.nq, n = A.n, S = A.S, G = A.G;
@@ -72,69 +88,22 @@ __global__ __launch_bounds__(512, 2) void k_scan_long(const LongArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
-    // XCD-aware remap (as k_scan): the G query groups that stream one split sit on ONE XCD.
+    // XCD-aware block map: the G query groups that stream one corpus split sit on ONE XCD (blocks b and b + 8 share an
+    // XCD and its L2: the split is fetched from HBM once and re-read from that L2 by the other groups; speed only, never
+    // correctness).  gpx < G -- an XCD serving fewer groups and more splits, so that its query images (800 KB a group
+    // at d = 1600) stay L2-resident -- was measured in round 4: 1-4 % SLOWER (L2 hit rate 71 % as it is; the queries
+    // are not what misses), so the plan keeps gpx = G.
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
-    const int split = xcd * (S >> 3) + slot / G;
-    const int g = slot % G;
+    const int gpx = A.gpx, nteam = G / gpx;                       // XCD teams: team t serves groups [t gpx, (t + 1) gpx)
+    const int team = xcd % nteam, xi = xcd / nteam;               // this XCD's team and its index inside the team
+    const int splits_per_xcd = (S * G >> 3) / gpx;
+    const int split = xi * splits_per_xcd + slot / gpx;
+    const int g = team * gpx + slot % gpx;
     int j_lo = split * A.tiles_per_split, j_hi = j_lo + A.tiles_per_split;
     if (j_hi > A.tile_count) j_hi = A.tile_count;
     if (j_lo >= j_hi) return;                           // whole workgroup: no barrier below is skipped by part of it
 
-    // wave layout: 4 query groups of 64 (two MFMA B operands: queries r and 32 + r of the group) x 2 halves of the
-    // row tile (128 rows = four 32-row blocks): every fragment read from LDS feeds two MFMAs (24 ds_read_b128 per
-    // slab and wave for 32 MFMAs; 32 queries x 256 rows per wave would need 36)
-    const int wq = wave & 3, wr = wave >> 2;
-    const int q0 = g * LT_Q + wq * 64 + r, q1 = q0 + 32;
-    const float thr0 = q0 < nq ? A.thr[q0] : INFINITY;          // padding lanes never keep anything
-    const float thr1 = q1 < nq ? A.thr[q1] : INFINITY;
-
-    // ---- staging: a slab is [256 rows][128 B] of the corpus tile followed by [256 queries][128 B]; 1 KiB pieces
-    // (8 rows x 8 chunks); chunk c of row t sits at chunk slot c ^ ((t >> 1) & 7): with 128-byte rows two rows share
-    // a 256-byte bank row, and this key makes every 16-lane group of a ds_read_b128 (16 consecutive rows, one chunk)
-    // cover all 64 banks exactly once.  64 pieces per slab: wave w takes pieces w, w + 8, ... -- its first four are
-    // corpus rows, its last four queries; the per-lane source addresses (without the slab offset) are kept in
-    // registers: the queries' for the whole kernel, the rows' per tile.
-    // The DMA takes a uniform 64-bit base (the tile's / the query group's first row + the slab offset: scalar adds)
-    // and a per-lane 32-bit offset kept in registers: no vector address arithmetic per piece.
-    const unsigned lds_base = (unsigned)(unsigned long)(lptr_c)smem;
-    unsigned off_q[4], off_c[4];
-    const char* q_base = Qb + (size_t)g * LT_Q * rb;
-    const char* c_base = Cb;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int t = ((wave + 8 * i) << 3) + (lane >> 3);       // query row of the tile: pieces 32 + wave + 8 i
-        int tq = t;
-        if (g * LT_Q + tq > nq - 1) tq = nq - 1 - g * LT_Q;      // short query batch: clamp (the group holds >= 1 query)
-        off_q[i] = (unsigned)tq * (unsigned)rb + (unsigned)(((lane & 7) ^ ((t >> 1) & 7)) * 16);
-    }
-    auto set_tile = [&](int tile) __attribute__((always_inline)) {
-        c_base = Cb + (size_t)tile * LT_ROWS * rb;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int t = ((wave + 8 * i) << 3) + (lane >> 3);   // corpus row of the tile: pieces wave + 8 i
-            int tc = t;
-            if ((long)tile * LT_ROWS + tc > (long)n - 1) tc = (int)((long)n - 1 - (long)tile * LT_ROWS);   // ragged last tile: clamp
-            off_c[i] = (unsigned)tc * (unsigned)rb + (unsigned)(((lane & 7) ^ ((t >> 1) & 7)) * 16);
-        }
-    };
-    auto stage = [&](int buf, int slab) __attribute__((always_inline)) {
-        const size_t so = (size_t)slab * LT_BK;
-        const unsigned long cbv = (unsigned long)(c_base + so), qbv = (unsigned long)(q_base + so);
-        // (readfirstlane returns int: without the unsigned casts a low word with bit 31 set sign-extends into the high word)
-        const unsigned long cbs = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cbv >> 32)) << 32) | (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)cbv);
-        const unsigned long qbs = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(qbv >> 32)) << 32) | (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)qbv);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * LT_STAGE + ((i < 4 ? 0 : 32) + wave + 8 * (i & 3)) * 1024);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
-                         : : "v"(i < 4 ? off_c[i & 3] : off_q[i & 3]), "s"(dst), "s"(i < 4 ? cbs : qbs) : "memory");
-        }
-    };
-
-    const f32x16 zero = {0};
-    f32x16 acc[4][2];
-    const int keyq0 = ((wq * 64 + r) >> 1) & 7, keyq1 = ((wq * 64 + 32 + r) >> 1) & 7;
     const int total_steps = (j_hi - j_lo) * nslab;             // slab steps of this split
     // tile j of the level = corpus tile floor(j * total_tiles / tile_count), advanced incrementally (one division here
     // instead of a 64-bit scalar division sequence per tile)
@@ -146,31 +115,100 @@ __global__ __launch_bounds__(512, 2) void k_scan_long(const LongArgs A) {
         if (fr >= A.tile_count) { fr -= A.tile_count; ++tl; }
     };
 
-    set_tile(tile);
-    stage(0, 0);
-    int step = 0;
+    // ---- LDS: a slab is [256 rows][128 B] of one operand in 1 KiB pieces (8 rows x 8 chunks); chunk c of row t sits
+    // at chunk slot c ^ ((t >> 1) & 7): with 128-byte rows two rows share a 256-byte bank row, and this key makes every
+    // 16-lane group of a ds_read_b128 (16 consecutive rows, one chunk) cover all 64 banks exactly once.  Corpus slabs
+    // in a ring of three slots, query slabs in a ring of two behind them.
+    // Steps run over (tile, slab) pairs; step t reads corpus slot t % 3 and query slot t % 2; ONE barrier per step.
+    //
+    // LOADER WAVES (round 4).  Twelve waves: eight matrix waves and four loaders, one per SIMD.  A DMA instruction costs
+    // its wave 100-200 cycles of issue in this loop (MI355X_MICROARCH.md, LDS-DMA piece issue cost) -- with every wave
+    // issuing its eight pieces of each slab, ~1.2 k cycles per wave and slab in which it issued no matrix instruction,
+    // against 1 k of its own matrix work: the pipe was 43 % busy with the waves parked half of their time.  Here the
+    // matrix waves issue NO vector-memory instruction inside the K loop (their counter only sees the tile epilogue's
+    // stores), the loaders nothing else: sixteen pieces per loader and step -- the query pieces of step t + 1, then the
+    // corpus pieces of step t + 2 -- and `vmcnt(8)` at the top of a step leaves exactly the youngest eight (corpus,
+    // t + 2) in flight while everything step t + 1 reads is known to have landed before the barrier releases it.
+    const unsigned lds_base = (unsigned)(unsigned long)(lptr_c)smem;
+    if (wave >= 8) {
+        const int lw = wave - 8;
+        unsigned off_q[LT_NP], off_c[LT_NP];
+        const char* q_base = Qb + (size_t)g * LT_Q * rb;
+        const char* c_base = Cb;
+#pragma unroll
+        for (int i = 0; i < LT_NP; ++i) {
+            const int t = ((lw + LT_LOADERS * i) << 3) + (lane >> 3);    // query row of the tile: piece lw + 4 i
+            int tq = t;
+            if (g * LT_Q + tq > nq - 1) tq = nq - 1 - g * LT_Q;          // short query batch: clamp (the group holds >= 1 query)
+            off_q[i] = (unsigned)tq * (unsigned)rb + (unsigned)(((lane & 7) ^ ((t >> 1) & 7)) * 16);
+        }
+        auto set_tile = [&](int tl) __attribute__((always_inline)) {
+            c_base = Cb + (size_t)tl * LT_ROWS * rb;
+#pragma unroll
+            for (int i = 0; i < LT_NP; ++i) {
+                const int t = ((lw + LT_LOADERS * i) << 3) + (lane >> 3);   // corpus row of the tile
+                int tc = t;
+                if ((long)tl * LT_ROWS + tc > (long)n - 1) tc = (int)((long)n - 1 - (long)tl * LT_ROWS);   // ragged last tile: clamp
+                off_c[i] = (unsigned)tc * (unsigned)rb + (unsigned)(((lane & 7) ^ ((t >> 1) & 7)) * 16);
+            }
+        };
+        // one operand slab: a uniform 64-bit base (first row + slab offset: scalar adds) and per-lane 32-bit offsets
+        auto stage = [&](const char* base, const unsigned (&off)[LT_NP], int slot_idx, int slab) __attribute__((always_inline)) {
+            const unsigned long bv = (unsigned long)(base + (size_t)slab * LT_BK);
+            // (readfirstlane returns int: without the unsigned casts a low word with bit 31 set sign-extends into the high word)
+            const unsigned long bs = ((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bv >> 32)) << 32) | (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)bv);
+#pragma unroll
+            for (int i = 0; i < LT_NP; ++i) {
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + slot_idx * LT_HALF + (lw + LT_LOADERS * i) * 1024);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                             : : "v"(off[i]), "s"(dst), "s"(bs) : "memory");
+            }
+        };
+        int itile = tile, ifrac = tile_frac, islab = 0, ibuf = 0;   // next corpus slab to fetch and its ring slot
+        auto issue_rows = [&]() __attribute__((always_inline)) {
+            if (islab == 0) set_tile(itile);
+            stage(c_base, off_c, ibuf, islab);
+            ibuf = ibuf == 2 ? 0 : ibuf + 1;
+            if (++islab == nslab) { islab = 0; next_tile(itile, ifrac); }
+        };
+        issue_rows();
+        stage(q_base, off_q, 3, 0);
+        if (total_steps > 1) issue_rows();
+        int qslab = 1 % nslab;                                      // query slab of step + 1
+        for (int step = 0; step < total_steps; ++step) {
+            if (step + 2 > total_steps - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (LT_NP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (LT_NP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __syncthreads();                                        // step's slabs are there; the slots of step - 1 are free
+            if (step + 1 < total_steps) stage(q_base, off_q, 3 + ((step & 1) ^ 1), qslab);
+            if (step + 2 < total_steps) issue_rows();               // into slot (step + 2) % 3, read last in step - 1
+            qslab = qslab + 1 == nslab ? 0 : qslab + 1;
+        }
+        return;                                                     // (the matrix waves' epilogues hold no barrier)
+    }
+
+    // ---- matrix waves: 4 query groups of 64 (two MFMA B operands: queries r and 32 + r of the group) x 2 halves of
+    // the row tile (128 rows = four 32-row blocks): every fragment read from LDS feeds two MFMAs (24 ds_read_b128 per
+    // slab and wave for 32 MFMAs; 32 queries x 256 rows per wave would need 36)
+    const int wq = wave & 3, wr = wave >> 2;
+    const int q0 = g * LT_Q + wq * 64 + r, q1 = q0 + 32;
+    const float thr0 = q0 < nq ? A.thr[q0] : INFINITY;          // padding lanes never keep anything
+    const float thr1 = q1 < nq ? A.thr[q1] : INFINITY;
+    const f32x16 zero = {0};
+    f32x16 acc[4][2];
+    const int keyq0 = ((wq * 64 + r) >> 1) & 7, keyq1 = ((wq * 64 + 32 + r) >> 1) & 7;
+    int step = 0, bufa = 0;                                     // bufa = step % 3
     for (int j = j_lo; j < j_hi; ++j) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) { acc[b][0] = zero; acc[b][1] = zero; }
         for (int s = 0; s < nslab; ++s, ++step) {
-            const int buf = step & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current slab have landed
-            __syncthreads();                                    // ... everyone's have, and the other buffer is free
-            // The next slab's DMA (eight pieces, a few hundred cycles of issue): waves 0-3 issue it before their MFMAs,
-            // waves 4-7 -- their SIMD partners -- after the first half of theirs, so that one partner's issue burst
-            // runs beside the other's matrix work instead of both bursts leaving the pipe idle together.
-            auto issue_next = [&]() __attribute__((always_inline)) {
-                if (step + 1 < total_steps) {
-                    if (s + 1 == nslab) { int tl = tile, fr = tile_frac; next_tile(tl, fr); set_tile(tl); stage(buf ^ 1, 0); }
-                    else stage(buf ^ 1, s + 1);
-                }
-            };
-            if (wave < 4) issue_next();
-            const char* rows = smem + buf * LT_STAGE;
-            const char* qs = rows + LT_ROWS * LT_BK;
+            const int bufb = step & 1;
+            __syncthreads();                                    // the loaders have seen this step's slabs land
+            const char* rows = smem + bufa * LT_HALF;
+            const char* qs = smem + (3 + bufb) * LT_HALF;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (u == 2 && wave >= 4) issue_next();
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(qs + (wq * 64 + r) * LT_BK + ((2 * u + h) ^ keyq0) * 16);
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(qs + (wq * 64 + 32 + r) * LT_BK + ((2 * u + h) ^ keyq1) * 16);
                 f32x4 a[4];
@@ -190,6 +228,7 @@ __global__ __launch_bounds__(512, 2) void k_scan_long(const LongArgs A) {
                     }
                 }
             }
+            bufa = bufa == 2 ? 0 : bufa + 1;
         }
         // ---- tile epilogue: acc[b][s][jj] is (corpus row tile * 256 + 128 wr + 32 b + (jj & 3) + 8 (jj >> 2) + 4 h,
         // query r (s = 0) / 32 + r (s = 1) of the wave's 64)
@@ -364,6 +403,13 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     LongArgs a;
     a.Qimg = q_scan; a.C = c_scan; a.nq = (int)nq; a.n = (int)n; a.d = d; a.G = (int)((nq + LT_Q - 1) / LT_Q);
     a.total_tiles = total_tiles; a.cap = cap; a.thr = thr; a.cnt = cnt; a.cand = cand;
+    // groups per XCD (block map of k_scan_long): all of them (fewer measured slower, see the kernel); the switch stays
+    // for A/B runs
+    a.gpx = a.G;
+    if (a.G == 2 || a.G == 4 || a.G == 8) {
+        static const int gpx_env = getenv("SSS_LONG_GPX") ? atoi(getenv("SSS_LONG_GPX")) : 0;
+        if (gpx_env > 0 && a.G % gpx_env == 0 && 8 % (a.G / gpx_env) == 0) a.gpx = gpx_env;
+    }
     static bool attr_done[MAX_DEVICES][2] = {};
     const int dev = current_device();
     for (int lv = levels - 1; lv >= 0; --lv) {
@@ -380,15 +426,15 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
         if (last && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(status), 1, (size_t)nq, st) != hipSuccess) { set_error("ip_topk_long: memset failed"); return SSS_EHIP; }
         rc = launch_thr_prepare(t, st);                                     // thresholds from column k-1 of D_out; counters zeroed
         if (rc) return rc;
-        const size_t lds = 2 * (size_t)LT_STAGE;
+        const size_t lds = LT_LDS_BYTES;
         const int ti = scan_dtype == DT_F16 ? 0 : 1;
         if (!attr_done[dev][ti]) {
             if (ti == 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_long<DT_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scan_long<DT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_done[dev][ti] = true;
         }
-        if (ti == 0) hipLaunchKernelGGL(k_scan_long<DT_F16>, dim3(a.S * a.G), dim3(512), lds, st, a);
-        else hipLaunchKernelGGL(k_scan_long<DT_BF16>, dim3(a.S * a.G), dim3(512), lds, st, a);
+        if (ti == 0) hipLaunchKernelGGL(k_scan_long<DT_F16>, dim3(a.S * a.G), dim3(LT_THREADS), lds, st, a);
+        else hipLaunchKernelGGL(k_scan_long<DT_BF16>, dim3(a.S * a.G), dim3(LT_THREADS), lds, st, a);
         rc = check_launch("k_scan_long");
         if (rc) return rc;
         rc = last ? launch_select_all(t, st) : launch_bound_from_scan(t, st);
