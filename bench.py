@@ -292,6 +292,7 @@ class Bench:
                     step()
                 torch.cuda.synchronize()
                 engine.unproven.zero_()
+                L.sss_scan_boot_expired(1)           # reset the diagnostic counter (synchronises: outside the timed region)
                 if profile:
                     _lib.check(L.sss_profile_enable(1), "profile_enable")
                 if world > 1:
@@ -321,6 +322,11 @@ class Bench:
                 res, elapsed, _ = timed_region(step_sync, steps, warmup)
             # snapshot: D / I are the sharded index's own result buffers, which the stage timings below overwrite
             emb, D, I = res[0], res[1].clone(), res[2].clone()
+            # waves whose bounded wait for the shared threshold ran out in the timed searches (sss.h: sss_scan_boot_expired):
+            # anything but 0 means the launch's workgroups were not co-resident and the figure below is not the kernel's
+            boot_expired = int(L.sss_scan_boot_expired(1))
+            if boot_expired != 0:
+                self.say(f"[{sp.name}] WARNING: bootstrap wait expired in {boot_expired} waves during the timed region")
             rung_q, exhaustive_q = index.last_rescan_queries, index.last_fallback_queries     # of the last (synchronous) step
             tot_ms, launches = ctypes.c_double(0), ctypes.c_int(0)
             _lib.check(L.sss_profile_read(ctypes.byref(tot_ms), ctypes.byref(launches)), "profile_read")
@@ -388,7 +394,7 @@ class Bench:
                 "dtype": "bf16x3" if split else "f16" if f16 else sp.dtype, "scan": mode, "timed_api": api,
                 "recall_at_10": round(sr.recall_at_k(I_got, Ir, k), 6), "ids_bit_exact": bool(np.array_equal(I_got, Ir)),
                 "max_score_err": float(np.abs(D_got - Dr).max()), "recall_queries_checked": nrq, "unproven_queries": unproven,
-                "stage_ms": stage, "incl_graph_build": incl, "collectives_ms": coll,
+                "bootstrap_wait_expired": boot_expired, "stage_ms": stage, "incl_graph_build": incl, "collectives_ms": coll,
                 "last_step_rung_queries": rung_q if step is step_sync else None,
                 "last_step_exhaustive_queries": exhaustive_q if step is step_sync else None,
                 "items_bit_exact": items_exact,
@@ -461,7 +467,7 @@ class Bench:
     def leg_summary(self, leg):
         """A leg's keys for a `configs` / `fast_path` object."""
         keys = ("dtype", "scan", "value", "ms_per_step", "timed_api", "recall_at_10", "ids_bit_exact", "max_score_err",
-                "recall_queries_checked", "unproven_queries", "stage_ms", "arithmetic", "roofline")
+                "recall_queries_checked", "unproven_queries", "bootstrap_wait_expired", "stage_ms", "arithmetic", "roofline")
         out = {kk: leg[kk] for kk in keys}
         out["unit"] = "queries/s"
         out["index_bytes_per_gpu"] = leg["index_bytes"]
@@ -653,7 +659,7 @@ def main():
                                        if args.force_collectives else "single GPU")},
             "recall_at_10": m["recall_at_10"], "ids_bit_exact": m["ids_bit_exact"], "max_score_err": m["max_score_err"],
             "recall_queries_checked": m["recall_queries_checked"], "unproven_queries": m["unproven_queries"],
-            "stage_ms": m["stage_ms"],
+            "bootstrap_wait_expired": m["bootstrap_wait_expired"], "stage_ms": m["stage_ms"],
             **({"value_incl_graph_build": m["incl_graph_build"]["value"],
                 "ms_per_step_incl_graph_build": m["incl_graph_build"]["ms_per_step"],
                 "incl_graph_build_note": f"the same step started from the flat action table (native graph build on the device + its two small "

@@ -63,8 +63,8 @@ assert src.count("        mfma_sub(i & 1, sub, next_tile);\n") == 2          # t
 src = src.replace("        mfma_sub(i & 1, sub, next_tile);\n",
     "        const unsigned long long mm0 = __builtin_amdgcn_s_memtime();\n        mfma_sub(i & 1, sub, next_tile);\n"
     "        if (threadIdx.x == 0 && blockIdx.x == 0 && i < 96) g_w[384 + i] += __builtin_amdgcn_s_memtime() - mm0;\n")
-src = sub1(src, "            if (i > nb && i <= ntiles) publish(cls_live);\n            tau_fetch();                        // lands under this tile's MFMAs\n",
-    "            const unsigned long long pp0 = __builtin_amdgcn_s_memtime();\n            if (i > nb && i <= ntiles) publish(cls_live);\n"
+src = sub1(src, "            publish(cls_live);                  // (before the fetch: an atomic behind the two DMA instructions waits for them)\n            tau_fetch();                        // lands under this tile's MFMAs\n",
+    "            const unsigned long long pp0 = __builtin_amdgcn_s_memtime();\n            publish(cls_live);\n"
     "            const unsigned long long pp1 = __builtin_amdgcn_s_memtime();\n            tau_fetch();\n"
     "            if (threadIdx.x == 0 && blockIdx.x == 0 && i < 96) { g_w[480 + i] = pp1 - pp0; g_w[576 + i] = __builtin_amdgcn_s_memtime() - pp1; }\n")
 src = src.replace("__device__ unsigned long long g_w[288];", "__device__ unsigned long long g_w[672];")

@@ -4,7 +4,7 @@ import sys, os, ctypes, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sessionsimilaritysearch_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsss_tl.so")
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("SSS_TL_LIB", "libsss_tl.so"))
 import torch
 from sessionsimilaritysearch_amd.index import FlatIndex, normalize_
 

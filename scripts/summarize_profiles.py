@@ -5,11 +5,11 @@ reads for `roofline.traffic` -- every entry stamped with the sha256 of the csrc/
 import csv, hashlib, json, os, re, shutil, sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out", "prof_" + tag), os.path.join(root, "profiles")
 sha = hashlib.sha256(open(os.path.join(root, "sessionsimilaritysearch_amd", "csrc", "scan.hip"), "rb").read()).hexdigest()[:16]
-for name in ("bench_default", "bench_split", "bench_c4_10m", "bench_c5_bf16", "bench_c3", "encoder", "search_shapes"):
+for name in ("bench_default", "bench_split", "bench_force_collectives", "bench_c4_10m", "bench_c5_bf16", "bench_c3", "encoder", "search_shapes"):
     if os.path.exists(f"{src}/{name}_kernel_stats.csv"):
         shutil.copy(f"{src}/{name}_kernel_stats.csv", f"{dst}/{tag}_{name}_kernel_stats.csv")
     lj = f"{src}/{name}_line.json"
@@ -36,10 +36,18 @@ def summarize(name):
     if not os.path.exists(path):
         return {}
     agg = defaultdict(list)
-    for r in csv.DictReader(open(path)):
+    rows = list(csv.DictReader(open(path)))
+    # k_scan_long runs once per sample level of a search (three at 1M x 1600, K = 100), always in the same order: the
+    # dispatches are labelled by their position in that cycle, so that the LAST level -- the full scan -- has a line of its own
+    long_ids = sorted({int(r["Dispatch_Id"]) for r in rows if "k_scan_long" in r["Kernel_Name"]})
+    level_of = {d: i % 3 + 1 for i, d in enumerate(long_ids)}
+    for r in rows:
         kn = r["Kernel_Name"]
-        if "k_scan" in kn or "k_select" in kn:
-            agg[(kn.split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if "k_scan" in kn or "k_select" in kn or "k_bound_from_scan" in kn:
+            name_ = kn.split("(")[0]
+            if "k_scan_long" in kn:
+                name_ += f" level {level_of[int(r['Dispatch_Id'])]} of 3"
+            agg[(name_, r["Counter_Name"])].append(float(r["Counter_Value"]))
     with open(f"{dst}/{tag}_{name}.csv", "w") as f:
         f.write("kernel,counter,launches,mean_per_launch\n")
         for (k, c), v in sorted(agg.items()):
@@ -48,8 +56,9 @@ def summarize(name):
 
 
 fetch, write = summarize("pmc_fetch"), summarize("pmc_write")
-for name in ("pmc_mfma", "pmc_issue", "pmc_mfma_c5"):
+for name in ("pmc_mfma", "pmc_issue", "pmc_mfma_c5", "pmc_long_tcc", "pmc_long_sq", "pmc_long_sq2", "pmc_long_fetch"):
     summarize(name)
+fetch4 = summarize("pmc_fetch_c4")
 fetch_split, fetch5 = summarize("pmc_fetch_split"), summarize("pmc_fetch_c5")
 n1, nq1, d1 = 1000000, 1024, 128
 doc = ("HBM bytes per launch of the scan kernel from rocprofv3 --pmc passes (scripts/collect_profiles.sh). FETCH_SIZE / "
@@ -73,5 +82,8 @@ entry(f"f32:{d1}:{nq1}:{n1}", fetch.get(("f32", "FETCH_SIZE")), write.get(("f32"
       f"profiles/{tag}_pmc_fetch.csv + {tag}_pmc_write.csv")
 entry(f"split:{d1}:{nq1}:{n1}", fetch_split.get(("split", "FETCH_SIZE")), None, n1 * d1 * 4 + nq1 * d1 * 4, f"profiles/{tag}_pmc_fetch_split.csv")
 entry("bf16:256:4096:10000000", fetch5.get(("bf16", "FETCH_SIZE")), None, 10000000 * 256 * 2 + 4096 * 256 * 2, f"profiles/{tag}_pmc_fetch_c5.csv")
+n4 = 10000000
+entry(f"f32:{d1}:{nq1}:{n4}", fetch4.get(("f32", "FETCH_SIZE")), None, n4 * d1 * 4 + nq1 * d1 * 4, f"profiles/{tag}_pmc_fetch_c4.csv")
+entry(f"f16:{d1}:{nq1}:{n4}", fetch4.get(("f16", "FETCH_SIZE")), None, n4 * d1 * 2 + nq1 * d1 * 4, f"profiles/{tag}_pmc_fetch_c4.csv")
 json.dump(traffic, open(f"{dst}/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))

@@ -37,7 +37,10 @@ constexpr int MAX_SLOTS = 128;  // admission-threshold slots per query (J <= MAX
 // A query's slot words start SLOT_STRIDE words apart whatever J is: the 1024 lines of a 1024-query batch then spread
 // over 512 KB of address space -- and with it over the memory channels -- instead of sitting in 64 contiguous KB that
 // every workgroup of the launch polls, fetches and hits with agent-scope atomics at the same moment (the bootstrap).
-constexpr int SLOT_STRIDE = MAX_SLOTS;
+#ifndef SSS_SLOT_STRIDE
+#define SSS_SLOT_STRIDE MAX_SLOTS
+#endif
+constexpr int SLOT_STRIDE = SSS_SLOT_STRIDE;
 constexpr unsigned ORD_NEG_INF = 0x007FFFFFu;   // f2ord(-inf); slot value 0 = "never written"
 
 static inline int elem_bytes(int dtype) { return (dtype == DT_BF16 || dtype == DT_F16) ? 2 : 4; }

@@ -146,9 +146,17 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
     // pair publishes ONE value -- the better of its two lane maxima, by lane h = 0: half the agent-scope atomics (at the
     // bootstrap 128 instead of 256 per query line, which all arrive within a microsecond and serialise at the line's
     // memory channel).  cert > 1: a class per lane list, as the lists certify `cert` rows each.
+#ifdef SSS_EXP_NOPAIR
+    const bool pair_pub = false;
+#else
     const bool pair_pub = A.cert == 1;
+#endif
     if (use_tau) {
-        cls_live = pair_pub ? (unsigned)split & 15u : (unsigned)(2 * split + h) % (unsigned)A.Ju;
+        // (split + split / 16: with the append form's 128 splits the low four bits of `split` alone would put the workgroups
+        //  dispatched first -- the lower half of the grid, one per CU -- in classes 0-7 and their co-resident partners,
+        //  which lose the SIMD arbitration and reach the end of the bootstrap tile ~10 us later, in classes 8-15: every
+        //  wave then waits for the slow half before it has a threshold.  Mixed, each class has members of both halves.)
+        cls_live = pair_pub ? (unsigned)(split + (split >> 4)) & 15u : (unsigned)(2 * split + h) % (unsigned)A.Ju;
         my_half = A.slots + (size_t)q_ld * SLOT_STRIDE + h * (J >> 1);
     }
     // Threshold word of the query from its J slots.  Synchronous form (bootstrap wait; J > 16): each lane of the
@@ -455,6 +463,10 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
     // f32 scan (15 us per tile) keeps refreshing every tile.
     constexpr bool TAU_EVERY_TILE = DT == DT_F32 || TR >= 512;
     auto refresh_at = [&](int i) {
+        // (no refresh in the tile right behind the bootstrap: the wave has just polled its threshold, and the first DMA
+        //  fetch of the slot lines -- while every CU's bootstrap atomics are still draining at the memory side -- took
+        //  ~25 k cycles to issue: per-tile stamps, round 4)
+        if (i == 1 && boot && !TAU_EVERY_TILE) return false;
         if (TAU_EVERY_TILE || i <= 4) return true;
         const int sh = 30 - __builtin_clz(i);              // i = (2 or 3) << sh  <=>  its low sh bits are zero
         return (i & ((1 << sh) - 1)) == 0;
@@ -552,6 +564,8 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
             const int row_base = tile * TR;
             const bool ragged = row_base + TR > n;              // wave-uniform, last tile of the corpus only
             const bool live = i >= nb;
+            // (unrolled: a single copy of the sub-step -- `#pragma unroll 1`, 6.4 k lines of ISA instead of 11.3 k, the
+            //  rare path's ~20 KB of code once instead of twice -- measured the same at 1M rows and 5 % SLOWER at 10M)
 #pragma unroll
             for (int sub = 0; sub < H; ++sub) {
                 mfma_sub(i & 1, sub, next_tile);
