@@ -15,9 +15,11 @@ for nsess, n in ((1024, 1000000), (512, 500000), (256, 250000), (128, 125000)):
     c = torch.randn((n, 128), device=dev, generator=g); normalize_(c)
     idx = FlatIndex(128, "ip", dev).adopt(c); idx.prepare(10)
     sh = ShardedFlatIndex(HipEngine(idx), dev)
+    qall = torch.randn((1024, 128), device=dev, generator=g); normalize_(qall)      # the gathered batch: every rank searches ALL queries
     def step():
-        emb = enc(qb, l2_normalize=True)
-        return sh.search_async(emb, 10)
+        emb = enc(qb, l2_normalize=True)             # this rank's nq / G sessions
+        qall[:nsess] = emb                           # (stands in for the all-gather landing the slices in the full batch)
+        return sh.search_async(qall, 10)
     for _ in range(10): step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
