@@ -454,14 +454,14 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
     const int T = niter * H;
     long row0_of_step = 0;                      // first corpus row of the current step
     // The threshold moves fast at first and then ever more slowly, and a stale one only admits extra candidates.  A
-    // refresh is not cheap in a 16-bit scan: its two LDS-DMA instructions (and the publish's atomic) queue behind the
-    // tile traffic of the CU's memory pipe -- ~3 k cycles per wave, half a 128-row tile (per-tile stamps, DESIGN.md
-    // 5.1).  With tau near the R-th best of the i tiles' rows seen so far, ~R / i rows per query pass per tile-time and
-    // a threshold stale by D tiles admits ~R D / i^2 more: the cost of refreshing every D tiles, c_r / D + c_p D / i^2
-    // per tile, is least at D ~ i -- so the 16-bit scans refresh at i = 1, 2, 3, 4 and then at 2 and 3 times the powers
-    // of two (6, 8, 12, 16, 24, ...: 12 refreshes of a 61-tile split instead of 21, 18 of 610 instead of 158).  The
-    // f32 scan (15 us per tile) keeps refreshing every tile.
-    constexpr bool TAU_EVERY_TILE = DT == DT_F32 || TR >= 512;
+    // refresh is not cheap: its two LDS-DMA instructions (and the publish's atomic) queue behind the tile traffic of the
+    // CU's memory pipe -- ~3 k cycles per wave, half a 128-row tile of a 16-bit scan (per-tile stamps).
+    // With tau near the R-th best of the i tiles' rows seen so far, ~R / i rows per query pass per tile-time and a
+    // threshold stale by D tiles admits ~R D / i^2 more: the cost of refreshing every D tiles, c_r / D + c_p D / i^2
+    // per tile, is least at D ~ i -- so every scan refreshes at i = 2, 3, 4 and then at 2 and 3 times the powers of
+    // two (6, 8, 12, 16, 24, ...: 12 refreshes of a 61-tile split instead of 21, 18 of 610 instead of 158).  The f32
+    // scan (15 us per tile) refreshed every tile until round 4; the same schedule takes 2 % off it (4 % at 125 k rows).
+    constexpr bool TAU_EVERY_TILE = TR >= 512;
     auto refresh_at = [&](int i) {
         // (no refresh in the tile right behind the bootstrap: the wave has just polled its threshold, and the first DMA
         //  fetch of the slot lines -- while every CU's bootstrap atomics are still draining at the memory side -- took
