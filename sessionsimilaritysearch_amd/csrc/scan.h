@@ -121,6 +121,8 @@ struct ThrArgs {
     float* D_out;                   // [nq, k]: row q's k-th entry is read (lower bound), rows of resolved queries are rewritten
     long* I_out;
     int* status;                    // [nq]: set to 0 for resolved queries
+    int keep = 0;                   // k_thr_prepare: 1 = keep the rows already kept that pass the NEW threshold (compacted in place)
+                                    //                instead of starting from an empty array (sss_ip_topk_long: disjoint levels)
 };
 int launch_thr_prepare(const ThrArgs& a, hipStream_t st);
 int launch_select_all(const ThrArgs& a, hipStream_t st);

@@ -47,6 +47,8 @@ struct LongArgs {
     int gpx;                        // query groups that share an XCD (block map below); divides G, G / gpx divides 8
     int dense;                      // sample level (many rows kept per lane and tile): aggregated appends
     int tile_count;                 // tiles this level scans: tile j of the level = corpus tile j * total_tiles / tile_count
+    int skip_R;                     // > 0: the level scans the tile_count corpus tiles that are NOT multiples of skip_R, in order
+                                    //      (the complement of a level that took every skip_R-th tile: DISJOINT LEVELS, host side)
     int total_tiles, tiles_per_split, cap;
     const float* thr;               // [nq] per-query threshold in the scan's domain
     unsigned* cnt;                  // [nq] rows kept so far
@@ -107,10 +109,18 @@ __global__ __launch_bounds__(LT_THREADS, (LT_THREADS + 255) / 256) void k_scan_l
     const int total_steps = (j_hi - j_lo) * nslab;             // slab steps of this split
     // tile j of the level = corpus tile floor(j * total_tiles / tile_count), advanced incrementally (one division here
     // instead of a 64-bit scalar division sequence per tile)
+    // (skip_R > 0: the j-th tile that is not a multiple of R is (j / (R - 1)) R + 1 + j % (R - 1); `tile_frac` then holds
+    //  tile % R and a step that lands on a multiple of R moves one further)
+    const int skip_R = A.skip_R;
     const int t_quo = A.total_tiles / A.tile_count, t_rem = A.total_tiles % A.tile_count;
-    int tile = (int)((long)j_lo * A.total_tiles / A.tile_count);
-    int tile_frac = (int)((long)j_lo * A.total_tiles % A.tile_count);
+    int tile = skip_R > 0 ? (j_lo / (skip_R - 1)) * skip_R + 1 + j_lo % (skip_R - 1) : (int)((long)j_lo * A.total_tiles / A.tile_count);
+    int tile_frac = skip_R > 0 ? 1 + j_lo % (skip_R - 1) : (int)((long)j_lo * A.total_tiles % A.tile_count);
     auto next_tile = [&](int& tl, int& fr) __attribute__((always_inline)) {
+        if (skip_R > 0) {
+            ++tl;
+            if (++fr == skip_R) { fr = 1; ++tl; }
+            return;
+        }
         tl += t_quo; fr += t_rem;
         if (fr >= A.tile_count) { fr -= A.tile_count; ++tl; }
     };
@@ -412,9 +422,32 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     }
     static bool attr_done[MAX_DEVICES][2] = {};
     const int dev = current_device();
+    // DISJOINT LEVELS (three levels and more).  The last sample used to be scanned twice: once as a sample, once more as
+    // part of the whole corpus -- 9 % of the matrix work at 1M x 1600, K = 100.  Now the last sample takes EVERY R-th
+    // tile (R = the planned ratio, rounded, >= 2) and the final level only the tiles in between: the rows the sample kept
+    // stay in the query's array, pruned by k_thr_prepare to those that pass the final threshold (its `keep` mode; the
+    // final threshold is the tighter one, so nothing above it was ever dropped), and the final level appends behind
+    // them.  Together they are exactly the rows of the whole corpus above the final threshold -- what k_select_all's
+    // proof needs -- and there are fewer of them (the sample's rows are filtered by the final threshold now).
+    int R = 0;
+    if (levels >= 3) {
+        R = (int)((double)total_tiles / (double)level_tiles[1] + 0.5);
+        if (R < 2) R = 0;                              // (ratio below 1.5: the planned sample is most of the corpus -- keep the plain form)
+    }
     for (int lv = levels - 1; lv >= 0; --lv) {
-        const int tiles = level_tiles[lv];
+        int tiles = level_tiles[lv];
         const bool last = lv == 0;
+        a.total_tiles = total_tiles;
+        a.skip_R = 0;
+        t.keep = 0;
+        if (R > 0 && lv == 1) {                        // every R-th tile: the proportional map with total = R * count
+            tiles = (total_tiles + R - 1) / R;
+            a.total_tiles = R * tiles;
+        } else if (R > 0 && last) {                    // the tiles in between
+            tiles = total_tiles - (total_tiles + R - 1) / R;
+            a.skip_R = R;
+            t.keep = 1;
+        }
         a.tile_count = tiles;
         a.dense = last ? 0 : 1;
         int S = (256 / a.G) & ~7;

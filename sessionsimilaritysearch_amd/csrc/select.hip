@@ -27,7 +27,12 @@ constexpr int FS_CAP = 2048;       // candidates a wave stages in LDS (more -> u
 constexpr int FS_K2 = 32;          // candidates the wave-per-query kernel can re-score (its second chance widens K2 <= 16 up to this)
 constexpr int FS_COL = 16;         // candidate keys a lane keeps in registers (64 x 16 = 1024 candidates; more -> columns in LDS)
 constexpr int SEL_MAX_K2 = 512;
-constexpr int SA_ROWS = 128;       // k_select_all: survivors re-scored per group (one thread each)
+#ifndef SSS_SA_ROWS_SMALL
+#define SSS_SA_ROWS_SMALL 256
+#endif
+constexpr int SA_ROWS_SMALL = SSS_SA_ROWS_SMALL;   // k_select_all: survivors re-scored per group (one thread each): the first launch (<= 2048 kept rows) --
+                                                   //   k + a few dozen survivors are ONE group up to k = 200-odd (a second group doubles the workgroup's time)
+constexpr int SA_ROWS_FULL = 128;                  //   ... the full-capacity launch (128 KB of keys leave room for no more)
 constexpr int SA_BYTES = 128;      //               bytes of every row staged through LDS per step
 constexpr int SORT_THREADS = 256;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -571,16 +576,35 @@ __global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
     if (i >= A.nsel) return;
     const int q = A.qsel[i];
     double B, unscale;
-    query_bound(A, q, lane, B, unscale);
-    if (lane != 0) return;
+    query_bound(A, q, lane, B, unscale);                                    // (every lane ends up with the same B / unscale)
     const double lb = (double)A.D_out[(size_t)q * A.k + A.k - 1];          // -FLT_MAX when no k-th score is known
     // rows the scan does NOT keep have scan score <= thr, hence exact score <= thr * unscale + B < lb - ulp32(lb)
     const double t = (lb - B - 2.4e-7 * fabs(lb) - 1e-44) / unscale;
     float thr = (float)t;                                                   // round to nearest, then step below
     if ((double)thr >= t) thr = nextafterf(thr, -INFINITY);
     if (!(lb > -3.0e38)) thr = -INFINITY;
-    A.thr[i] = thr;
-    A.cnt[i] = 0u;
+    if (!A.keep) {
+        if (lane == 0) { A.thr[i] = thr; A.cnt[i] = 0u; }
+        return;
+    }
+    // keep: the rows kept so far were kept under an OLDER, lower threshold over tiles the next scan will not visit
+    // again; those that pass the new one stay (compacted in place, in order: a lane writes at or below the index it
+    // read, and the whole wave has read a chunk before any of it is written).  An overflowed array stays overflowed.
+    const unsigned M = A.cnt[i];
+    if (lane == 0) A.thr[i] = thr;
+    if (M > (unsigned)A.cap) return;
+    unsigned long long* ck = const_cast<unsigned long long*>(A.cand) + (size_t)i * A.cap;
+    unsigned out = 0u;
+    for (unsigned c0 = 0; c0 < M; c0 += 64) {
+        const unsigned c = c0 + lane;
+        const unsigned long long key = c < M ? ck[c] : 0ull;
+        const bool kp = c < M && key_score(key) > thr;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(kp);
+        const unsigned pos = out + (unsigned)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (kp) ck[pos] = key;
+        out += (unsigned)__builtin_popcountll(mask);
+    }
+    if (lane == 0) A.cnt[i] = out;
 }
 
 // descending bitonic sort of keys[0 .. M2) (M2 a power of two) by the whole workgroup
@@ -676,6 +700,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bound_from_scan(const ThrArgs 
 // Launched twice: first with a SMALL LDS footprint (`cap_lds` = 2048 keys: several workgroups per CU -- the common
 // case of a few hundred kept rows), then with the full capacity for the queries the first launch had to skip
 // (`second`: resolved queries return at once).
+template <int SA_ROWS>
 __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, int cap_pow2, int second) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);             // [cap_pow2] kept rows (scan keys)
@@ -859,18 +884,23 @@ int launch_select_all(const ThrArgs& a, hipStream_t st) {
     const int rb = a.d * elem_bytes(a.dtype);
     int cap_pow2 = 64;
     while (cap_pow2 < a.cap) cap_pow2 <<= 1;
-    const size_t stage = (size_t)SA_ROWS * (SA_BYTES + 16);           // the re-score's staging tile
+    // the re-score's staging tile (rows of 1024 bytes and more; shorter rows are walked by a thread each)
+    const size_t stage = rb < 1024 ? 0 : (size_t)SA_ROWS_FULL * (SA_BYTES + 16);
+    const size_t stage_small = rb < 1024 ? 0 : (size_t)SA_ROWS_SMALL * (SA_BYTES + 16);
     const size_t lds = 2 * (size_t)cap_pow2 * 8 + ((rb + 15) & ~15) + stage;   // kept keys + survivors + the query row + the tile
     if (lds > 156 * 1024) { set_error("select_all: candidate capacity %d / row of %d bytes too large", a.cap, rb); return SSS_EINVAL; }
     static bool done[MAX_DEVICES] = {};
     const int dev = current_device();
     if (!done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_all), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_all<SA_ROWS_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_all<SA_ROWS_FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
         done[dev] = true;
     }
     const int small = cap_pow2 < 2048 ? cap_pow2 : 2048;
-    hipLaunchKernelGGL(k_select_all, dim3((unsigned)a.nsel), dim3(SORT_THREADS), 2 * (size_t)small * 8 + ((rb + 15) & ~15) + stage, st, a, small, 0);
-    if (small < cap_pow2) hipLaunchKernelGGL(k_select_all, dim3((unsigned)a.nsel), dim3(SORT_THREADS), lds, st, a, cap_pow2, 1);
+    // (k <= 64: k + a few dozen survivors fit one 128-row group, and a 256-row group would fetch twice the clamped copies)
+    if (a.k > 64) hipLaunchKernelGGL(k_select_all<SA_ROWS_SMALL>, dim3((unsigned)a.nsel), dim3(SORT_THREADS), 2 * (size_t)small * 8 + ((rb + 15) & ~15) + stage_small, st, a, small, 0);
+    else hipLaunchKernelGGL(k_select_all<SA_ROWS_FULL>, dim3((unsigned)a.nsel), dim3(SORT_THREADS), 2 * (size_t)small * 8 + ((rb + 15) & ~15) + stage, st, a, small, 0);
+    if (small < cap_pow2) hipLaunchKernelGGL(k_select_all<SA_ROWS_FULL>, dim3((unsigned)a.nsel), dim3(SORT_THREADS), lds, st, a, cap_pow2, 1);
     return check_launch("k_select_all");
 }
 

@@ -160,6 +160,8 @@ def test_small_corpus_large_k_uses_exhaustive_and_is_exact(cuda):
     (64, 70_001, 1600, 10),       # ragged last tile, small k (one big factor between the levels)
     (33, 20_000, 320, 500),       # shortest long row (640-byte f16 rows), large k
     (100, 30_000, 2048, 1),
+    (50, 300_000, 320, 100),      # three levels: the last sample takes every 6th tile, the final level the tiles in between
+    (37, 450_001, 320, 100),      # ... every 7th, ragged last tile
 ])
 def test_long_rows_take_the_k_tiled_scan(cuda, nq, n, d, k):
     rng = np.random.default_rng(nq + n + d)
