@@ -121,6 +121,8 @@ struct ThrArgs {
     float* D_out;                   // [nq, k]: row q's k-th entry is read (lower bound), rows of resolved queries are rewritten
     long* I_out;
     int* status;                    // [nq]: set to 0 for resolved queries
+    double* qb = nullptr;           // optional [nsel][2] cache of the queries' (error bound, unscale): written by the first kernel
+    int qb_ready = 0;               //   that computes them (qb_ready == 0), read by the later ones (sss_ip_topk_long: five kernels a search)
     int keep = 0;                   // k_thr_prepare: 1 = keep the rows already kept that pass the NEW threshold (compacted in place)
                                     //                instead of starting from an empty array (sss_ip_topk_long: disjoint levels)
 };

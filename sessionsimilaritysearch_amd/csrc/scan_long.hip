@@ -338,7 +338,7 @@ static bool long_shape_ok(int d, int exact_dtype, int scan_dtype) {
 size_t ip_topk_long_workspace_bytes(long nq, long n, int d, int dtype) {
     const int scan = dtype == DT_F32 ? DT_F16 : DT_BF16;
     if (nq <= 0 || n <= 0 || !long_shape_ok(d, dtype, scan)) return 0;
-    return al256((size_t)nq * d * 2) + al256((size_t)nq * 4) * 3 + (size_t)nq * LONG_CAP * 8;
+    return al256((size_t)nq * d * 2) + al256((size_t)nq * 4) * 3 + al256((size_t)nq * 16) + (size_t)nq * LONG_CAP * 8;
 }
 
 
@@ -365,6 +365,7 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     int* qsel = reinterpret_cast<int*>(w);       w += al256((size_t)nq * 4);
     float* thr = reinterpret_cast<float*>(w);    w += al256((size_t)nq * 4);
     unsigned* cnt = reinterpret_cast<unsigned*>(w); w += al256((size_t)nq * 4);
+    double* qb = reinterpret_cast<double*>(w);   w += al256((size_t)nq * 16);       // (error bound, unscale) per query: computed once
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(w);
 
     const void* q_scan = q;
@@ -410,6 +411,7 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     t.Q = q; t.C = c_exact; t.qsel = qsel; t.nsel = (int)nq; t.d = d; t.dtype = exact_dtype; t.k = k; t.cap = cap;
     t.scan_dtype = scan_dtype; t.corpus_shift = corpus_shift; t.corpus_resid = corpus_resid; t.corpus_max_norm = corpus_max_norm;
     t.id_offset = id_offset; t.thr = thr; t.cnt = cnt; t.cand = cand; t.D_out = D_out; t.I_out = I_out; t.status = status;
+    t.qb = qb; t.qb_ready = 0;
     LongArgs a;
     a.Qimg = q_scan; a.C = c_scan; a.nq = (int)nq; a.n = (int)n; a.d = d; a.G = (int)((nq + LT_Q - 1) / LT_Q);
     a.total_tiles = total_tiles; a.cap = cap; a.thr = thr; a.cnt = cnt; a.cand = cand;
@@ -459,6 +461,7 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
         if (last && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(status), 1, (size_t)nq, st) != hipSuccess) { set_error("ip_topk_long: memset failed"); return SSS_EHIP; }
         rc = launch_thr_prepare(t, st);                                     // thresholds from column k-1 of D_out; counters zeroed
         if (rc) return rc;
+        t.qb_ready = 1;                                                     // (the first prepare has filled the cache)
         const size_t lds = LT_LDS_BYTES;
         const int ti = scan_dtype == DT_F16 ? 0 : 1;
         if (!attr_done[dev][ti]) {

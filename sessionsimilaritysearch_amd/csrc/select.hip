@@ -547,7 +547,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
 // k_thr_prepare: one wave per selected query: its threshold in the scan's domain, counter zeroed.
 // B (scan error bound) and unscale (scan score -> score factor) of query row q, computed by ONE wave (all 64 lanes
 // call it; every lane returns the same values).
-__device__ __forceinline__ void query_bound(const ThrArgs& A, int q, int lane, double& B, double& unscale) {
+__device__ __forceinline__ void query_bound(const ThrArgs& A, int i, int q, int lane, double& B, double& unscale) {
+    if (A.qb != nullptr && A.qb_ready) { B = A.qb[2 * (size_t)i]; unscale = A.qb[2 * (size_t)i + 1]; return; }   // (selected query i = row q)
     const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
     const char* qrow = reinterpret_cast<const char*>(A.Q) + (size_t)q * rb;
     double qn2 = 0.0;
@@ -568,6 +569,7 @@ __device__ __forceinline__ void query_bound(const ThrArgs& A, int q, int lane, d
     }
     B = err_bound(A.d, A.scan_dtype, sqrt(qn2), (double)A.corpus_max_norm, (double)A.corpus_resid, sqrt(rq2));
     unscale = A.scan_dtype == DT_F16 ? ldexp(1.0, -(A.corpus_shift + f16_shift(q_amax))) : 1.0;
+    if (A.qb != nullptr && lane == 0) { A.qb[2 * (size_t)i] = B; A.qb[2 * (size_t)i + 1] = unscale; }
 }
 
 __global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
     if (i >= A.nsel) return;
     const int q = A.qsel[i];
     double B, unscale;
-    query_bound(A, q, lane, B, unscale);                                    // (every lane ends up with the same B / unscale)
+    query_bound(A, i, q, lane, B, unscale);                                 // (every lane ends up with the same B / unscale)
     const double lb = (double)A.D_out[(size_t)q * A.k + A.k - 1];          // -FLT_MAX when no k-th score is known
     // rows the scan does NOT keep have scan score <= thr, hence exact score <= thr * unscale + B < lb - ulp32(lb)
     const double t = (lb - B - 2.4e-7 * fabs(lb) - 1e-44) / unscale;
@@ -629,14 +631,15 @@ __device__ __forceinline__ void sort_desc(unsigned long long* keys, int M2, int 
 // that still match the prefix, then the bin holding the k-th from the top (one wave: four bins a lane, a suffix
 // sum by shuffles) -- four passes over the keys instead of a sort of up to 8192 of them (round 3; it was 32 one-bit
 // passes, 3 barriers each).  s_hist: 260 shared words; every thread returns the same value.
-__device__ __forceinline__ unsigned kth_largest_ord(const unsigned long long* keys, int M, int k, int tid, unsigned* s_hist) {
+template <typename OrdAt>
+__device__ __forceinline__ unsigned kth_largest_of(OrdAt ord_at, int M, int k, int tid, unsigned* s_hist) {
     unsigned prefix = 0u, mask = 0u;
     unsigned kk = (unsigned)k;                      // rank, from the top, inside the bucket that matches the prefix
     for (int shift = 24; shift >= 0; shift -= 8) {
         s_hist[tid] = 0u;
         __syncthreads();
         for (int x = tid; x < M; x += SORT_THREADS) {
-            const unsigned o = (unsigned)(keys[x] >> 32);
+            const unsigned o = ord_at(x);
             if ((o & mask) == prefix) atomicAdd(&s_hist[(o >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -667,21 +670,32 @@ __device__ __forceinline__ unsigned kth_largest_ord(const unsigned long long* ke
     return prefix;
 }
 
+__device__ __forceinline__ unsigned kth_largest_ord(const unsigned long long* keys, int M, int k, int tid, unsigned* s_hist) {
+    return kth_largest_of([&](int x) { return (unsigned)(keys[x] >> 32); }, M, k, tid, s_hist);
+}
+
 // k_bound_from_scan (sss_ip_topk_long, intermediate levels): no row is read.  At least k of the kept rows have a
 // scan score >= the k-th largest kept scan score s_k, so at least k rows have an exact score >= s_k * unscale - B:
 // a valid LOWER BOUND of the query's true k-th score, written to column k-1 of its row of D_out (where the next
 // level's k_thr_prepare reads it).  Left unchanged when the kept rows overflowed the capacity or are fewer than k.
 __global__ __launch_bounds__(SORT_THREADS) void k_bound_from_scan(const ThrArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned* ords = reinterpret_cast<unsigned*>(smem);                 // [cap] score ordinals of the kept rows
     __shared__ unsigned s_hist[260];
     const int i = blockIdx.x, tid = threadIdx.x;
     const int q = A.qsel[i];
     const int k = A.k;
     const unsigned M = A.cnt[i];
     if (M > (unsigned)A.cap || (int)M < k) return;
-    const unsigned sk = kth_largest_ord(A.cand + (size_t)i * A.cap, (int)M, k, tid, s_hist);
+    // the four radix passes run over LDS: read from the array in global memory they moved 4 x 64 KB per query --
+    // 270 MB for the first level of a 1024-query search (every one of its 8192 sampled rows is kept), 70 us
+    const unsigned long long* ck = A.cand + (size_t)i * A.cap;
+    for (int x = tid; x < (int)M; x += SORT_THREADS) ords[x] = (unsigned)(ck[x] >> 32);
+    __syncthreads();
+    const unsigned sk = kth_largest_of([&](int x) { return ords[x]; }, (int)M, k, tid, s_hist);
     if (tid < 64) {
         double B, unscale;
-        query_bound(A, q, tid, B, unscale);
+        query_bound(A, i, q, tid, B, unscale);
         if (tid == 0) {
             const double lb = (double)ord2f(sk) * unscale - B;
             float f = (float)lb;
@@ -727,7 +741,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
         const unsigned sk_o = kth_largest_ord(keys, (int)M, k, tid, s_hist);
         if (tid < 64) {
             double B, unscale;
-            query_bound(A, q, tid, B, unscale);
+            query_bound(A, i, q, tid, B, unscale);
             if (tid == 0) {
                 const double sk = (double)ord2f(sk_o);
                 const double c = sk - (2.0 * B + 2.4e-7 * fabs(sk * unscale) + 1e-44) / unscale;
@@ -876,7 +890,7 @@ int launch_thr_prepare(const ThrArgs& a, hipStream_t st) {
 }
 
 int launch_bound_from_scan(const ThrArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_bound_from_scan, dim3((unsigned)a.nsel), dim3(SORT_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_bound_from_scan, dim3((unsigned)a.nsel), dim3(SORT_THREADS), (size_t)a.cap * 4, st, a);     // (cap <= 8192: 32 KB)
     return check_launch("k_bound_from_scan");
 }
 
