@@ -212,6 +212,33 @@ def test_long_rows_duplicates_ties_and_sorted_corpus(cuda):
     assert idx.last_fallback_queries == 3 and np.array_equal(I, np.tile(np.arange(10), (3, 1)))
 
 
+def test_long_rows_disjoint_levels_with_ties_and_a_sorted_corpus(cuda):
+    """Three levels (300 k rows of 640 scan bytes, K = 100): the last sample takes every 6th tile and the final level the
+    tiles in between, the rows the sample kept are pruned in place and stay.  Exact ties that straddle sample and
+    non-sample tiles (ascending id decides), a corpus sorted by score for one query (all of its neighbours in the last
+    tiles), and one with the best rows in the FIRST tiles: all exact, all proven by the scan itself."""
+    rng = np.random.default_rng(83)
+    n, d, k = 300_000, 320, 100
+    c = _unit(rng, n, d)
+    hot = _unit(rng, 3, d)
+    for j in range(3):                                      # 160 copies of each hot row, scattered over the tiles
+        c[rng.choice(n, 160, replace=False)] = hot[j]
+    q = _unit(rng, 24, d)
+    q[:3] = hot                                             # their top 100 are 100 of 160 exact ties
+    q[3:6] = sr.normalize(hot + 0.05 * rng.standard_normal((3, d)).astype(np.float32)).astype(np.float32)
+    idx = _index(c, cuda)
+    D, I = idx.search(q, k)
+    Dr, Ir = sr.search_exact(q, c, k)
+    assert idx.last_scan == "long" and idx.last_rescan_queries == 0
+    assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+    for order in (1, -1):
+        c2 = np.ascontiguousarray(c[np.argsort(order * (c @ q[7]))])
+        idx = _index(c2, cuda)
+        D, I = idx.search(q[6:12], k)
+        Dr, Ir = sr.search_exact(q[6:12], c2, k)
+        assert np.array_equal(I, Ir) and np.array_equal(D, Dr)
+
+
 def test_long_rows_bf16_index_and_id_offset(cuda):
     from sessionsimilaritysearch_amd.index import FlatIndex
     rng = np.random.default_rng(82)
