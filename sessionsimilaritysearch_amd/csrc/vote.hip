@@ -19,6 +19,7 @@ namespace sss {
 
 constexpr int VT = 256;                 // threads per query
 constexpr int VOTE_MAX_ENTRIES = 16384; // expanded (neighbour, item) pairs per query (128 KiB of LDS)
+constexpr int VOTE_SMALL_ENTRIES = 4096; // ... the first launch's share (32 KiB: four workgroups per CU)
 constexpr unsigned long long TAKEN = 1ull << 15;
 
 struct Best { double w; int seq; int pos; };
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(VT) void k_item_vote(const float* __restrict__ D, c
                                                   const long* __restrict__ items_ptr, const int* __restrict__ items,
                                                   long id_offset, long n_sessions, int K, int cap,
                                                   long* __restrict__ out_items, double* __restrict__ out_w,
-                                                  int* __restrict__ status) {
+                                                  int* __restrict__ status, int cap_full, int second) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];     // [cap]
     __shared__ int s_scan[VT];
     __shared__ int s_total;
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(VT) void k_item_vote(const float* __restrict__ D, c
     __shared__ int s_bs[VT / 64], s_bp[VT / 64];
     __shared__ int s_winner_pos;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (second && status[q] != 2) return;                    // (whole workgroup) resolved by the first launch
     const float* Dq = D + (size_t)q * S;
     const long* Iq = I + (size_t)q * S;
     long* oi = out_items + (size_t)q * K;
@@ -65,6 +67,10 @@ __global__ __launch_bounds__(VT) void k_item_vote(const float* __restrict__ D, c
     int off = s_scan[tid] - mine;
     __syncthreads();
     total = s_total;
+    if (total > cap && total <= cap_full) {                  // first launch (small LDS footprint): the second one's share
+        if (tid == 0) status[q] = 2;
+        return;
+    }
     if (total > cap) {                                       // does not fit the LDS budget: tell the caller
         if (tid == 0) status[q] = 1;
         for (int i = tid; i < K; i += VT) { oi[i] = -1; if (out_w) out_w[(size_t)q * K + i] = 0.0; }
@@ -152,7 +158,11 @@ int item_vote(const float* D, const long* I, long nq, int S, const long* items_p
         set_error("item_vote: need nq, K > 0 and 0 < sample_size < 32768");
         return SSS_EINVAL;
     }
-    const int cap = VOTE_MAX_ENTRIES;
+    // Launched twice, like k_select_all: first with a SMALL LDS footprint (4096 expanded pairs = 32 KB: four workgroups
+    // per CU -- the usual few thousand pairs of a query; with the full 128 KB every workgroup had a CU to itself and
+    // 1024 queries ran in four rounds: 1.0 ms of config C3's step), then with the full capacity for the queries the first
+    // launch had to leave (status 2; the others return at once).
+    const int cap = VOTE_MAX_ENTRIES, cap_small = VOTE_SMALL_ENTRIES;
     static bool done[64] = {};
     int dev = 0; (void)hipGetDevice(&dev); if (dev < 0 || dev >= 64) dev = 0;
     if (!done[dev]) {
@@ -160,8 +170,10 @@ int item_vote(const float* D, const long* I, long nq, int S, const long* items_p
                                   (int)item_vote_lds_bytes(cap));
         done[dev] = true;
     }
+    hipLaunchKernelGGL(k_item_vote, dim3((unsigned)nq), dim3(VT), item_vote_lds_bytes(cap_small), st, D, I, S, items_ptr, items,
+                       id_offset, n_sessions, K, cap_small, out_items, out_w, status, cap, 0);
     hipLaunchKernelGGL(k_item_vote, dim3((unsigned)nq), dim3(VT), item_vote_lds_bytes(cap), st, D, I, S, items_ptr, items,
-                       id_offset, n_sessions, K, cap, out_items, out_w, status);
+                       id_offset, n_sessions, K, cap, out_items, out_w, status, cap, 1);
     return check_launch("k_item_vote");
 }
 

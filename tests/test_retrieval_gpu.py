@@ -56,6 +56,30 @@ def test_vote_sample_size_500(cuda):
     _check_vote(cuda, D, I, batch, 10)
 
 
+def test_vote_large_samples_take_the_second_launch(cuda):
+    """More expanded (neighbour, item) pairs than the first launch's 4096-entry footprint (sample size 1500, ~5 items a
+    session: ~7500 pairs) next to queries that fit it (most of their neighbours padded away): both launches, one result;
+    and a sample too large for the full 16384-entry capacity reports status 1."""
+    from sessionsimilaritysearch_amd.retrieval import SessionItems, knn_item_vote
+    rng = np.random.default_rng(52)
+    batch = S.build_batch(S.synthetic_actions(6000, 52, n_items=2000, n_query=65))
+    nq, Sn = 24, 1500
+    I = np.stack([rng.permutation(6000)[:Sn] for _ in range(nq)]).astype(np.int64)
+    D = -np.sort(-rng.uniform(0.3, 0.99, (nq, Sn)).astype(np.float32), axis=1)
+    I[::3, 400:] = -1                                                       # every third query: 400 neighbours (~2000 pairs)
+    _check_vote(cuda, D, I, batch, 10)
+    Sn = 6000                                                               # ~30 000 pairs: beyond the capacity
+    I = np.stack([rng.permutation(6000)[:Sn] for _ in range(4)]).astype(np.int64)
+    D = -np.sort(-rng.uniform(0.3, 0.99, (4, Sn)).astype(np.float32), axis=1)
+    I[1, 300:] = -1
+    ds = SessionItems.from_batch(batch, cuda)
+    res = knn_item_vote(torch.from_numpy(D).to(cuda), torch.from_numpy(I).to(cuda), ds, 10, return_weights=True)
+    out, status = res[0].cpu().numpy(), res[2].cpu().numpy()
+    assert status.tolist() == [1, 0, 1, 1] and (out[0] == -1).all()
+    ref_i, _ = sr.knn_item_vote_weights(D[1], I[1], _items_of(batch), 10)
+    assert [int(v) for v in out[1]] == ref_i
+
+
 def test_config_c3_pipeline_small(cuda):
     """Config C3 in miniature: corpus = 4 prefix sub-sessions (25/50/75/100 % of the actions) of
     every session, embedded by the HIP encoder; query = the 50 % prefix; top-500 neighbours ->
