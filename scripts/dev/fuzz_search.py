@@ -9,6 +9,7 @@ from sessionsimilaritysearch_amd.index import FlatIndex
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+long_rows = len(sys.argv) > 3 and sys.argv[3] == "long"      # the K-tiled long-row search only: 2 - 5 levels, disjoint levels, ties
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda", 0)
 bad = 0
@@ -23,6 +24,14 @@ for case in range(cases):
     k = int(rng.choice([1, 5, 10, 10, 12, 13, 16, 17, 20, 21, 50, 100, 200, 500]))
     bf16 = d in (128, 256, 512) and rng.random() < 0.2
     flavour = str(rng.choice(["unit", "unit", "raw", "scaled", "dups", "adds"]))
+    if long_rows:
+        d = int(rng.choice([320, 512, 1024, 1600, 2048]))
+        n = int(rng.choice([9000, 70001, 170000, 300000, 450001, 800000]))
+        n = min(n, 480_000_000 // d)                            # <= 1.9 GB of float32 rows
+        nq = int(rng.choice([1, 31, 64, 200, 300]))
+        k = int(rng.choice([1, 10, 50, 100, 100, 200, 500, 1000]))
+        scan, bf16 = "auto", d <= 1024 and rng.random() < 0.2
+        flavour = str(rng.choice(["unit", "unit", "dups", "hot", "sorted", "scaled"]))
     c = rng.standard_normal((n, d)).astype(np.float32)
     q = rng.standard_normal((nq, d)).astype(np.float32)
     if flavour in ("unit", "dups", "adds"):
@@ -31,6 +40,13 @@ for case in range(cases):
         c *= np.float32(10.0 ** rng.uniform(-6, 6)); q *= np.float32(10.0 ** rng.uniform(-6, 6))
     if flavour == "dups" and n > 10:
         c[rng.integers(0, n, n // 3)] = c[rng.integers(0, n, n // 3)]
+    if flavour == "hot":                        # groups of exact ties at the top of some queries, scattered over the tiles
+        c, q = sr.normalize(c).astype(np.float32), sr.normalize(q).astype(np.float32)
+        for j in range(min(3, nq)):
+            c[rng.choice(n, int(rng.choice([3, 150, 700])), replace=False)] = q[j]
+    if flavour == "sorted":                     # the best rows of query 0 all at one end of the corpus
+        c, q = sr.normalize(c).astype(np.float32), sr.normalize(q).astype(np.float32)
+        c = np.ascontiguousarray(c[np.argsort((1 if rng.random() < 0.5 else -1) * (c @ q[0]))])
     if bf16:                                    # bf16 index: the contract is defined on the rounded vectors
         c = torch.from_numpy(c).to(torch.bfloat16).float().numpy()
         q = torch.from_numpy(q).to(torch.bfloat16).float().numpy()
