@@ -20,6 +20,9 @@
 //             and duplicate rows included -- so the canonical float64 re-score of all of it (k_select_all) IS the
 //             exact answer (status 0); a query with more than 8192 such rows keeps status 1 and goes to the
 //             exhaustive kernels.  The last sample is 1/r of the corpus: ~r k rows per query reach the re-score.
+//   With three levels and more the last sample and the final level are DISJOINT (host side, "DISJOINT LEVELS"): the
+//   sample takes every R-th tile, the final level the tiles in between, and the rows the sample kept stay (pruned in place
+//   to the final threshold) -- no tile is scanned twice.
 // Two to three passes, the last one dominant; no per-lane list, no shared threshold slots, no bootstrap.
 #include "scan.h"
 #include <cmath>
