@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/sel; mkdir -p $O
-timeout -k 10 900 python3 scripts/dev/fuzz_search.py 11 30 long > $O/fuzz_long.txt 2>&1; tail -4 $O/fuzz_long.txt
+timeout -k 10 400 python3 scripts/dev/fuzz_search.py 31 40 > $O/fuzz.txt 2>&1; tail -2 $O/fuzz.txt
 timeout -k 10 600 python -m pytest tests/test_search_gpu.py tests/test_search_fuzz_gpu.py -x -q > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
 tail -2 $O/tests.log
 bash scripts/dev/abn.sh 4 "libsss_base.so tree" 1024,125000,128,10,f16 1024,1000000,128,10,f16 1024,125000,128,10,f32mfma 1024,1000000,128,10,split > $O/ab.txt 2>&1
