@@ -43,7 +43,7 @@ def summarize(name):
     level_of = {d: i % 3 + 1 for i, d in enumerate(long_ids)}
     for r in rows:
         kn = r["Kernel_Name"]
-        if "k_scan" in kn or "k_select" in kn or "k_bound_from_scan" in kn:
+        if "k_scan" in kn or "k_select" in kn or "k_bound" in kn or "k_long_setup" in kn:
             name_ = kn.split("(")[0]
             if "k_scan_long" in kn:
                 name_ += f" level {level_of[int(r['Dispatch_Id'])]} of 3"

@@ -128,6 +128,11 @@ struct ThrArgs {
 };
 int launch_thr_prepare(const ThrArgs& a, hipStream_t st);
 int launch_select_all(const ThrArgs& a, hipStream_t st);
-int launch_bound_from_scan(const ThrArgs& a, hipStream_t st);   // intermediate levels of sss_ip_topk_long: bound only, no row read
+// sss_ip_topk_long's fused steps: everything a search needs before its first scan in ONE launch (f16 query image when
+// `qimg` is given, identity selection, D_out rows at -FLT_MAX, thresholds -inf, counters 0, status 1, the per-query
+// (error bound, unscale) cache), and the step between two levels in one launch (bound from the level just scanned ->
+// column k-1 of D_out -> the next level's threshold; counters zeroed, or -- a.keep -- the kept rows pruned in place).
+int launch_long_setup(const ThrArgs& a, int* qsel, void* qimg, hipStream_t st);
+int launch_bound_prepare(const ThrArgs& a, hipStream_t st);
 
 }  // namespace sss

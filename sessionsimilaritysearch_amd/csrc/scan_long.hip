@@ -13,7 +13,7 @@
 // passes.  The threshold comes from LEVELS of evenly spread row samples:
 //   level 1   a sample of up to `cap` rows (>= 2k), threshold -inf: every sampled row is kept; at least k of them have a scan
 //             score >= the k-th largest kept scan score s_k, hence an exact score >= s_k - (scan error bound): a
-//             valid LOWER BOUND of the true k-th score (k_bound_from_scan: a sort of scan scores, no row is read);
+//             valid LOWER BOUND of the true k-th score (k_bound_prepare: a selection over scan scores, no row is read);
 //   level i   a sample r <= `fmax` times larger scanned with threshold = (bound - error bound - one ulp): about
 //             k * fmax rows pass per query -> a tighter bound the same way;
 //   last      every row.  What passes is everything that can still reach the k-th score already known -- near ties
@@ -58,20 +58,8 @@ struct LongArgs {
     unsigned long long* cand;       // [nq][cap]
 };
 
-// f32 queries -> f16 image scaled by the query's own power of two (scan.h: f16_shift of its largest |element|) --
-// what k_scan's prologue does in registers; the select side (err_bound / k_thr_prepare) re-derives the same shift.
-__global__ __launch_bounds__(256) void k_query_f16(const float* __restrict__ q, int nq, int d, _Float16* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= nq) return;
-    const float* row = q + (size_t)i * d;
-    float amax = 0.f;
-    for (int kk = lane; kk < d; kk += 64) amax = fmaxf(amax, fabsf(row[kk]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    const int sh = f16_shift(amax);
-    for (int kk = lane; kk < d; kk += 64) out[(size_t)i * d + kk] = (_Float16)ldexpf(row[kk], sh);
-}
+// (the f16 image of f32 queries -- scaled by the query's own power of two, scan.h: f16_shift -- is written by
+//  select.hip: k_long_setup; the select side, err_bound / k_thr_prepare, re-derives the same shift)
 
 #ifndef SSS_LT_LOADERS
 #define SSS_LT_LOADERS 4
@@ -345,11 +333,6 @@ size_t ip_topk_long_workspace_bytes(long nq, long n, int d, int dtype) {
 }
 
 
-__global__ void k_iota(int* p, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = i;
-}
-
 int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, const void* c_scan, int corpus_shift,
                  float corpus_resid, long n, int d, int k, long id_offset, float corpus_max_norm, float* D_out, long* I_out,
                  int* status, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -371,17 +354,10 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     double* qb = reinterpret_cast<double*>(w);   w += al256((size_t)nq * 16);       // (error bound, unscale) per query: computed once
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(w);
 
-    const void* q_scan = q;
-    if (scan_dtype == DT_F16) {
-        hipLaunchKernelGGL(k_query_f16, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const float*>(q), (int)nq, d,
-                           reinterpret_cast<_Float16*>(qimg));
-        q_scan = qimg;
-    }
-    hipLaunchKernelGGL(k_iota, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, qsel, (int)nq);
-    // "no bound known": column k-1 = -FLT_MAX makes k_thr_prepare hand out a -inf threshold
-    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(D_out), (int)0xFF7FFFFFu, (size_t)nq * k, st) != hipSuccess) { set_error("ip_topk_long: memset failed"); return SSS_EHIP; }
-    int rc = check_launch("k_query_f16 / k_iota");
-    if (rc) return rc;
+    // (the f16 query image, the identity selection, D_out at "no bound known", thresholds, counters, status and the
+    //  per-query bound cache are written by ONE launch below, once the ThrArgs are filled: launch_long_setup)
+    const void* q_scan = scan_dtype == DT_F16 ? qimg : q;
+    int rc = SSS_OK;
 
     // ---- levels (descending in level_tiles, run in reverse).  The first sample is as large as the capacity allows with
     // the threshold at -inf (cap rows: every sampled row is kept) -- a 32-tile level costs the time of ONE tile, the chip
@@ -389,7 +365,7 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     // the whole corpus the tile counts grow by equal factors r <= fmax = cap / (4 k): about k * r rows pass a level's
     // threshold (2x margin below the capacity at r = fmax), the fewest levels that allows, and the factors balanced so
     // that the last sample is as small as it can be (1M x 1600, K = 100: 32, 353, 3907 tiles -- the samples add ~10 % to
-    // the matrix work; it was 1, 24, 488, 3907).  Intermediate levels read no row at all (k_bound_from_scan).
+    // the matrix work; it was 1, 24, 488, 3907).  Intermediate levels read no row at all (k_bound_prepare).
     const int total_tiles = (int)((n + LT_ROWS - 1) / LT_ROWS);
     int fmax = cap / (4 * k);
     if (fmax < 2) fmax = 2;
@@ -415,6 +391,9 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
     t.scan_dtype = scan_dtype; t.corpus_shift = corpus_shift; t.corpus_resid = corpus_resid; t.corpus_max_norm = corpus_max_norm;
     t.id_offset = id_offset; t.thr = thr; t.cnt = cnt; t.cand = cand; t.D_out = D_out; t.I_out = I_out; t.status = status;
     t.qb = qb; t.qb_ready = 0;
+    rc = launch_long_setup(t, qsel, scan_dtype == DT_F16 ? qimg : nullptr, st);
+    if (rc) return rc;
+    t.qb_ready = 1;
     LongArgs a;
     a.Qimg = q_scan; a.C = c_scan; a.nq = (int)nq; a.n = (int)n; a.d = d; a.G = (int)((nq + LT_Q - 1) / LT_Q);
     a.total_tiles = total_tiles; a.cap = cap; a.thr = thr; a.cnt = cnt; a.cand = cand;
@@ -444,14 +423,12 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
         const bool last = lv == 0;
         a.total_tiles = total_tiles;
         a.skip_R = 0;
-        t.keep = 0;
         if (R > 0 && lv == 1) {                        // every R-th tile: the proportional map with total = R * count
             tiles = (total_tiles + R - 1) / R;
             a.total_tiles = R * tiles;
         } else if (R > 0 && last) {                    // the tiles in between
             tiles = total_tiles - (total_tiles + R - 1) / R;
             a.skip_R = R;
-            t.keep = 1;
         }
         a.tile_count = tiles;
         a.dense = last ? 0 : 1;
@@ -461,10 +438,8 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
         a.S = S;
         a.tiles_per_split = (tiles + S - 1) / S;
         t.n = n;
-        if (last && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(status), 1, (size_t)nq, st) != hipSuccess) { set_error("ip_topk_long: memset failed"); return SSS_EHIP; }
-        rc = launch_thr_prepare(t, st);                                     // thresholds from column k-1 of D_out; counters zeroed
-        if (rc) return rc;
-        t.qb_ready = 1;                                                     // (the first prepare has filled the cache)
+        // (thresholds and counters of this level: written by launch_long_setup -- first level -- or by the previous level's
+        //  launch_bound_prepare)
         const size_t lds = LT_LDS_BYTES;
         const int ti = scan_dtype == DT_F16 ? 0 : 1;
         if (!attr_done[dev][ti]) {
@@ -476,7 +451,13 @@ int ip_topk_long(const void* q, long nq, const void* c_exact, int exact_dtype, c
         else hipLaunchKernelGGL(k_scan_long<DT_BF16>, dim3(a.S * a.G), dim3(LT_THREADS), lds, st, a);
         rc = check_launch("k_scan_long");
         if (rc) return rc;
-        rc = last ? launch_select_all(t, st) : launch_bound_from_scan(t, st);
+        if (last) rc = launch_select_all(t, st);
+        else {
+            // bound from this level's kept scan scores -> the next level's thresholds; the final level of a disjoint
+            // schedule keeps this (the last sample's) rows that pass them
+            t.keep = (R > 0 && lv == 1) ? 1 : 0;
+            rc = launch_bound_prepare(t, st);
+        }
         if (rc) return rc;
     }
     return SSS_OK;

@@ -572,28 +572,21 @@ __device__ __forceinline__ void query_bound(const ThrArgs& A, int i, int q, int 
     if (A.qb != nullptr && lane == 0) { A.qb[2 * (size_t)i] = B; A.qb[2 * (size_t)i + 1] = unscale; }
 }
 
-__global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= A.nsel) return;
-    const int q = A.qsel[i];
-    double B, unscale;
-    query_bound(A, i, q, lane, B, unscale);                                 // (every lane ends up with the same B / unscale)
-    const double lb = (double)A.D_out[(size_t)q * A.k + A.k - 1];          // -FLT_MAX when no k-th score is known
-    // rows the scan does NOT keep have scan score <= thr, hence exact score <= thr * unscale + B < lb - ulp32(lb)
+// The scan threshold that a known lower bound `lb` of the query's k-th score allows: rows the scan does NOT keep have
+// scan score <= thr, hence exact score <= thr * unscale + B < lb - ulp32(lb).  -inf when no bound is known (-FLT_MAX).
+__device__ __forceinline__ float thr_from_bound(double lb, double B, double unscale) {
     const double t = (lb - B - 2.4e-7 * fabs(lb) - 1e-44) / unscale;
     float thr = (float)t;                                                   // round to nearest, then step below
     if ((double)thr >= t) thr = nextafterf(thr, -INFINITY);
     if (!(lb > -3.0e38)) thr = -INFINITY;
-    if (!A.keep) {
-        if (lane == 0) { A.thr[i] = thr; A.cnt[i] = 0u; }
-        return;
-    }
-    // keep: the rows kept so far were kept under an OLDER, lower threshold over tiles the next scan will not visit
-    // again; those that pass the new one stay (compacted in place, in order: a lane writes at or below the index it
-    // read, and the whole wave has read a chunk before any of it is written).  An overflowed array stays overflowed.
+    return thr;
+}
+
+// keep mode (one wave): the rows kept so far were kept under an OLDER, lower threshold over tiles the next scan will not
+// visit again; those that pass the new one stay (compacted in place, in order: a lane writes at or below the index it
+// read, and the whole wave has read a chunk before any of it is written).  An overflowed array stays overflowed.
+__device__ __forceinline__ void prune_kept(const ThrArgs& A, int i, float thr, int lane) {
     const unsigned M = A.cnt[i];
-    if (lane == 0) A.thr[i] = thr;
     if (M > (unsigned)A.cap) return;
     unsigned long long* ck = const_cast<unsigned long long*>(A.cand) + (size_t)i * A.cap;
     unsigned out = 0u;
@@ -607,6 +600,42 @@ __global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
         out += (unsigned)__builtin_popcountll(mask);
     }
     if (lane == 0) A.cnt[i] = out;
+}
+
+__global__ __launch_bounds__(256) void k_thr_prepare(const ThrArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= A.nsel) return;
+    const int q = A.qsel[i];
+    double B, unscale;
+    query_bound(A, i, q, lane, B, unscale);                                 // (every lane ends up with the same B / unscale)
+    const float thr = thr_from_bound((double)A.D_out[(size_t)q * A.k + A.k - 1], B, unscale);    // -FLT_MAX when no k-th score is known
+    if (lane == 0) A.thr[i] = thr;
+    if (!A.keep) {
+        if (lane == 0) A.cnt[i] = 0u;
+        return;
+    }
+    prune_kept(A, i, thr, lane);
+}
+
+// sss_ip_topk_long, before the first scan: one wave per query (scan.h: launch_long_setup).
+__global__ __launch_bounds__(256) void k_long_setup(const ThrArgs A, int* __restrict__ qsel, _Float16* __restrict__ qimg) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= A.nsel) return;
+    if (qimg != nullptr) {                          // f32 queries -> f16 image scaled by the query's own power of two (scan.h f16_shift)
+        const float* row = reinterpret_cast<const float*>(A.Q) + (size_t)i * A.d;
+        float amax = 0.f;
+        for (int kk = lane; kk < A.d; kk += 64) amax = fmaxf(amax, fabsf(row[kk]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        const int sh = f16_shift(amax);
+        for (int kk = lane; kk < A.d; kk += 64) qimg[(size_t)i * A.d + kk] = (_Float16)ldexpf(row[kk], sh);
+    }
+    for (int j = lane; j < A.k; j += 64) A.D_out[(size_t)i * A.k + j] = -3.4028234663852886e38f;   // "no bound known"
+    double B, unscale;
+    query_bound(A, i, i, lane, B, unscale);         // fills the cache (A.qb_ready == 0 here)
+    if (lane == 0) { qsel[i] = i; A.thr[i] = -INFINITY; A.cnt[i] = 0u; A.status[i] = 1; }
 }
 
 // descending bitonic sort of keys[0 .. M2) (M2 a power of two) by the whole workgroup
@@ -674,11 +703,15 @@ __device__ __forceinline__ unsigned kth_largest_ord(const unsigned long long* ke
     return kth_largest_of([&](int x) { return (unsigned)(keys[x] >> 32); }, M, k, tid, s_hist);
 }
 
-// k_bound_from_scan (sss_ip_topk_long, intermediate levels): no row is read.  At least k of the kept rows have a
-// scan score >= the k-th largest kept scan score s_k, so at least k rows have an exact score >= s_k * unscale - B:
-// a valid LOWER BOUND of the query's true k-th score, written to column k-1 of its row of D_out (where the next
-// level's k_thr_prepare reads it).  Left unchanged when the kept rows overflowed the capacity or are fewer than k.
-__global__ __launch_bounds__(SORT_THREADS) void k_bound_from_scan(const ThrArgs A) {
+// k_bound_prepare (sss_ip_topk_long, between two levels; scan.h: launch_bound_prepare): no row is read.  At least k of
+// the kept rows have a scan score >= the k-th largest kept scan score s_k, so at least k rows have an exact score
+// >= s_k * unscale - B: a valid LOWER BOUND of the query's true k-th score, written to column k-1 of its row of D_out
+// (left unchanged when the kept rows overflowed the capacity or are fewer than k) -- and the next level's threshold
+// straight from it (what k_thr_prepare would compute in a launch of its own).  The four radix passes run over LDS: read
+// from the array in global memory they moved 4 x 64 KB per query -- 270 MB for the first level of a 1024-query search
+// (every one of its 8192 sampled rows is kept), 70 us.  One workgroup per query; the selection by all of it, the rest
+// by its first wave.
+__global__ __launch_bounds__(SORT_THREADS) void k_bound_prepare(const ThrArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* ords = reinterpret_cast<unsigned*>(smem);                 // [cap] score ordinals of the kept rows
     __shared__ unsigned s_hist[260];
@@ -686,23 +719,31 @@ __global__ __launch_bounds__(SORT_THREADS) void k_bound_from_scan(const ThrArgs 
     const int q = A.qsel[i];
     const int k = A.k;
     const unsigned M = A.cnt[i];
-    if (M > (unsigned)A.cap || (int)M < k) return;
-    // the four radix passes run over LDS: read from the array in global memory they moved 4 x 64 KB per query --
-    // 270 MB for the first level of a 1024-query search (every one of its 8192 sampled rows is kept), 70 us
-    const unsigned long long* ck = A.cand + (size_t)i * A.cap;
-    for (int x = tid; x < (int)M; x += SORT_THREADS) ords[x] = (unsigned)(ck[x] >> 32);
-    __syncthreads();
-    const unsigned sk = kth_largest_of([&](int x) { return ords[x]; }, (int)M, k, tid, s_hist);
-    if (tid < 64) {
-        double B, unscale;
-        query_bound(A, i, q, tid, B, unscale);
-        if (tid == 0) {
-            const double lb = (double)ord2f(sk) * unscale - B;
-            float f = (float)lb;
-            if ((double)f > lb) f = nextafterf(f, -INFINITY);              // round DOWN: stays a lower bound
-            if (f == f && f > A.D_out[(size_t)q * k + k - 1]) A.D_out[(size_t)q * k + k - 1] = f;
-        }
+    const bool have = M <= (unsigned)A.cap && (int)M >= k;              // (workgroup-uniform)
+    unsigned sk = 0u;
+    if (have) {
+        const unsigned long long* ck = A.cand + (size_t)i * A.cap;
+        for (int x = tid; x < (int)M; x += SORT_THREADS) ords[x] = (unsigned)(ck[x] >> 32);
+        __syncthreads();
+        sk = kth_largest_of([&](int x) { return ords[x]; }, (int)M, k, tid, s_hist);
     }
+    if (tid >= 64) return;
+    double B, unscale;
+    query_bound(A, i, q, tid, B, unscale);
+    float lbf = A.D_out[(size_t)q * k + k - 1];
+    if (have) {
+        const double lb = (double)ord2f(sk) * unscale - B;
+        float f = (float)lb;
+        if ((double)f > lb) f = nextafterf(f, -INFINITY);               // round DOWN: stays a lower bound
+        if (f == f && f > lbf) { lbf = f; if (tid == 0) A.D_out[(size_t)q * k + k - 1] = f; }
+    }
+    const float thr = thr_from_bound((double)lbf, B, unscale);
+    if (tid == 0) A.thr[i] = thr;
+    if (!A.keep) {
+        if (tid == 0) A.cnt[i] = 0u;
+        return;
+    }
+    prune_kept(A, i, thr, tid);
 }
 
 // k_select_all: one workgroup per selected query.  The kept rows are first pruned by SCAN score, before any row is
@@ -889,9 +930,14 @@ int launch_thr_prepare(const ThrArgs& a, hipStream_t st) {
     return check_launch("k_thr_prepare");
 }
 
-int launch_bound_from_scan(const ThrArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_bound_from_scan, dim3((unsigned)a.nsel), dim3(SORT_THREADS), (size_t)a.cap * 4, st, a);     // (cap <= 8192: 32 KB)
-    return check_launch("k_bound_from_scan");
+int launch_long_setup(const ThrArgs& a, int* qsel, void* qimg, hipStream_t st) {
+    hipLaunchKernelGGL(k_long_setup, dim3((unsigned)((a.nsel + 3) / 4)), dim3(256), 0, st, a, qsel, reinterpret_cast<_Float16*>(qimg));
+    return check_launch("k_long_setup");
+}
+
+int launch_bound_prepare(const ThrArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_bound_prepare, dim3((unsigned)a.nsel), dim3(SORT_THREADS), (size_t)a.cap * 4, st, a);     // (cap <= 8192: 32 KB)
+    return check_launch("k_bound_prepare");
 }
 
 int launch_select_all(const ThrArgs& a, hipStream_t st) {
