@@ -314,27 +314,33 @@ __global__ __launch_bounds__(RS_THREADS) void k_topk_radix(const float* __restri
 // rows are compacted IN ID ORDER by many workgroups (count per slab, scan, ordered write) and the select
 // then runs over the survivors.  More survivors than CP_CAP (rows sorted ascending, say): the select
 // falls back to the full row -- speed only, never correctness.
-constexpr int CP_HEAD = 65536;
+constexpr int CP_HEAD = 32768;        // sampled scores (their ordinals are staged in 128 KB of LDS: one fetch, four radix passes)
 constexpr int CP_SLAB = 65536;
 constexpr int CP_CAP = 131072;
 constexpr long CP_MIN_N = 262144;
 
 __global__ __launch_bounds__(RS_THREADS) void k_head_threshold(const float* __restrict__ scores, long n, int k, int metric,
                                                                unsigned* __restrict__ T0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned ords[];     // [head] ordinals of the sampled scores
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_need;
     const int f = blockIdx.x, tid = threadIdx.x;
     const float* s = scores + (size_t)f * n;
     const long head = n < CP_HEAD ? n : CP_HEAD;         // sample size; rows i * stride: an evenly spread sample
     const long stride = n / head;                        // (corpora are often ordered -- by session length, by prefix ...)
+    // the sample is fetched ONCE (every element its own cache line: with the four passes reading global memory this
+    // single workgroup spent 0.40 ms per query on 262 k scattered loads at 4M rows)
+    for (long i = tid; i < head; i += RS_THREADS) {
+        const float v = s[i * stride];
+        ords[i] = f2ord(metric == 0 ? v : -v);
+    }
     unsigned need = (unsigned)((long)k < head ? k : head), prefix = 0, mask = 0;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         for (int i = tid; i < 256; i += RS_THREADS) hist[i] = 0;
         __syncthreads();
         for (long i = tid; i < head; i += RS_THREADS) {
-            const float v = s[i * stride];
-            const unsigned key = f2ord(metric == 0 ? v : -v);
+            const unsigned key = ords[i];
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -498,7 +504,13 @@ int ip_topk_exhaustive(const void* q, const int* qsel, long nsel, const void* c,
         unsigned* cnt_eq = reinterpret_cast<unsigned*>(p);               p += (size_t)nsel * nslabs * 4;
         unsigned* T0 = reinterpret_cast<unsigned*>(p);                   p += (size_t)nsel * 4;
         unsigned* total = reinterpret_cast<unsigned*>(p);
-        hipLaunchKernelGGL(k_head_threshold, dim3((unsigned)nsel), dim3(RS_THREADS), 0, st, scores, n, k, metric, T0);
+        static bool head_attr[MAX_DEVICES] = {};
+        const int hdev = current_device();
+        if (!head_attr[hdev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_threshold), hipFuncAttributeMaxDynamicSharedMemorySize, CP_HEAD * 4);
+            head_attr[hdev] = true;
+        }
+        hipLaunchKernelGGL(k_head_threshold, dim3((unsigned)nsel), dim3(RS_THREADS), (size_t)CP_HEAD * 4, st, scores, n, k, metric, T0);
         hipLaunchKernelGGL(k_count_ge, dim3((unsigned)nslabs, (unsigned)nsel), dim3(256), 0, st, scores, n, metric, T0, nslabs, cnt_gt, cnt_eq);
         hipLaunchKernelGGL(k_scan_slabs, dim3((unsigned)nsel), dim3(64), 0, st, cnt_gt, cnt_eq, nslabs, n, k, total);
         hipLaunchKernelGGL(k_compact_ge, dim3((unsigned)nslabs, (unsigned)nsel), dim3(RS_THREADS), 0, st, scores, n, k, metric, T0, nslabs,
