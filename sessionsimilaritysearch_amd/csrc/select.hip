@@ -856,11 +856,45 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
         }
     }
     __syncthreads();
-    sort_desc(keys, K2, tid);
+    // Many more survivors than results (a query whose k-th neighbour sits in a group of thousands of identical rows: config
+    // C3's one-click prefix sessions): a bitonic sort of all K2 exact keys -- 91 barrier stages at K2 = 8192 -- was 0.3 of
+    // the 0.5 ms such a workgroup took.  The k best are SELECTED first (two radix descents: the k-th largest score ordinal,
+    // then, inside its tie group, the id word that completes the count -- keys are unique, so exactly k lie at or above the
+    // resulting key) and only they are sorted.
+    int Ks = 64;
+    while (Ks < k) Ks <<= 1;
+    const unsigned long long* outk = keys;
+    if (keep > 2 * Ks) {
+        const unsigned sk = kth_largest_of([&](int x) { return (unsigned)(keys[x] >> 32); }, keep, k, tid, s_hist);
+        if (tid == 0) s_keep = 0u;
+        __syncthreads();
+        unsigned gt = 0u;
+        for (int x = tid; x < keep; x += SORT_THREADS) gt += (unsigned)(keys[x] >> 32) > sk ? 1u : 0u;
+        if (gt) atomicAdd(&s_keep, gt);
+        __syncthreads();
+        const int need_eq = k - (int)s_keep;                            // >= 1: the k-th itself has ordinal sk
+        __syncthreads();
+        const unsigned lowk = kth_largest_of([&](int x) { const unsigned long long kx = keys[x]; return (unsigned)(kx >> 32) == sk ? (unsigned)kx : 0u; },
+                                             keep, need_eq, tid, s_hist);
+        const unsigned long long T = ((unsigned long long)sk << 32) | lowk;
+        if (tid == 0) s_keep = 0u;
+        __syncthreads();
+        for (int x = tid; x < keep; x += SORT_THREADS) {                // (surv: the survivors' scan keys are no longer needed)
+            const unsigned long long kx = keys[x];
+            if (kx >= T) surv[atomicAdd(&s_keep, 1u)] = kx;
+        }
+        __syncthreads();
+        for (int x = (int)s_keep + tid; x < Ks; x += SORT_THREADS) surv[x] = 0ull;
+        __syncthreads();
+        sort_desc(surv, Ks, tid);
+        outk = surv;
+    } else {
+        sort_desc(keys, K2, tid);
+    }
     float* Dq = A.D_out + (size_t)q * k;
     long* Iq = A.I_out + (size_t)q * k;
     for (int j = tid; j < k; j += SORT_THREADS) {
-        if (j < keep) { Dq[j] = key_score(keys[j]); Iq[j] = (long)key_id(keys[j]) + A.id_offset; }
+        if (j < keep) { Dq[j] = key_score(outk[j]); Iq[j] = (long)key_id(outk[j]) + A.id_offset; }
         else { Dq[j] = -3.4028234663852886e38f; Iq[j] = -1; }
     }
     if (tid == 0) A.status[q] = 0;
