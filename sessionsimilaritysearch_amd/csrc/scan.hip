@@ -564,6 +564,17 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
             const int row_base = tile * TR;
             const bool ragged = row_base + TR > n;              // wave-uniform, last tile of the corpus only
             const bool live = i >= nb;
+            if constexpr (THR) {
+                // a wave whose 32 query slots are all padding (the rung's compact query list rarely fills the 256 slots of
+                // a workgroup: ~100 unproven queries of a 1024-query batch leave waves 4-7 empty) stages its share of the
+                // tiles and keeps the barriers, nothing else: the three-pass split scan of the rung is bound by the matrix
+                // pipe, and an empty wave was taking half of its SIMD's
+                if (g * WGQ + wave * 32 >= nq) {
+                    if (next_tile >= 0) stage((i & 1) ^ 1, next_tile);
+                    tile_end(i);
+                    continue;
+                }
+            }
             // (unrolled: a single copy of the sub-step -- `#pragma unroll 1`, 6.4 k lines of ISA instead of 11.3 k, the
             //  rare path's ~20 KB of code once instead of twice -- measured the same at 1M rows and 5 % SLOWER at 10M)
 #pragma unroll
