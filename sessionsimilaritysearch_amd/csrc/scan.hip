@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
                     else lost = lost > key ? lost : key;
                 }
             }
-            if (lost != 0ull) atomicMax(A.maxlast + q_glob, lost);
+            if (lost != 0ull && A.maxlast != nullptr) atomicMax(A.maxlast + q_glob, lost);   // (threshold form: the count alone tells)
         }
         ecnt = need ? 0 : ecnt;
     };
@@ -591,13 +591,11 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
                 }
                 const float m = score_tree();
                 if (live && __builtin_amdgcn_ballot_w64(m > thr) != 0) {
-                    if constexpr (THR) {
-                        emit_block(acc0, row0 + 4 * h);
-                        emit_block(acc1, row0 + 32 + 4 * h);
-                    } else {
-                        append_block(acc0, row0 + 4 * h);
-                        append_block(acc1, row0 + 32 + 4 * h);
-                    }
+                    // (the threshold form used to hand every passing row to the candidate array with an atomic add of its own
+                    //  -- fine for the rung's few queries and tight thresholds; the sampled large-k search keeps thousands of
+                    //  rows per query: the append form's 4-entry register buffer, one atomic add per flush, serves both)
+                    append_block(acc0, row0 + 4 * h);
+                    append_block(acc1, row0 + 32 + 4 * h);
                 }
             }
             tile_end(i);
@@ -628,7 +626,7 @@ __global__ __launch_bounds__(NW * 64, AP ? 2 * (NW / 4) : NW / 4) void k_scan(co
         if (!defer && (unsigned)t % (unsigned)H == H - 1) tile_end((int)((unsigned)t / (unsigned)H));    // (rare implies t >= t_live)
         ++t;
     }
-    if constexpr (THR) return;
+    if constexpr (THR) { flush(ecnt > 0); return; }
     if constexpr (AP) flush(ecnt > 0);
     list_insert<KP>(ls, li, pend_s, pend_i);   // no-op for lanes with an empty slot (-inf)
     // ---- append the real entries to the query's compact candidate array (none in the append form: li stayed -1)
