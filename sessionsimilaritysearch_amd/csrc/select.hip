@@ -448,6 +448,73 @@ __global__ __launch_bounds__(256) void k_select_fast(const SelectArgs A) {
     }
 }
 
+// The k-th largest score ordinal (high word of the keys) among keys[0 .. M), k <= M, by the whole workgroup of
+// SORT_THREADS = 256 threads: a radix descent, eight bits a pass -- a 256-bin histogram (LDS atomics) of the keys
+// that still match the prefix, then the bin holding the k-th from the top (one wave: four bins a lane, a suffix
+// sum by shuffles) -- four passes over the keys instead of a sort of up to 8192 of them (round 3; it was 32 one-bit
+// passes, 3 barriers each).  s_hist: 260 shared words; every thread returns the same value.
+template <typename OrdAt>
+__device__ __forceinline__ unsigned kth_largest_of(OrdAt ord_at, int M, int k, int tid, unsigned* s_hist) {
+    unsigned prefix = 0u, mask = 0u;
+    unsigned kk = (unsigned)k;                      // rank, from the top, inside the bucket that matches the prefix
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        s_hist[tid] = 0u;
+        __syncthreads();
+        for (int x = tid; x < M; x += SORT_THREADS) {
+            const unsigned o = ord_at(x);
+            if ((o & mask) == prefix) atomicAdd(&s_hist[(o >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const unsigned h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
+            const unsigned mine = h0 + h1 + h2 + h3;
+            unsigned suf = mine;                    // sum over this lane and every higher one
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = (unsigned)__shfl_down((int)suf, o);
+                if (tid + o < 64) suf += v;
+            }
+            const unsigned above = suf - mine;
+            if (above < kk && suf >= kk) {          // the k-th from the top falls into this lane's four bins (exactly one lane)
+                unsigned cum = above;
+                int b = 3;
+                if (cum + h3 < kk) { cum += h3; b = 2; if (cum + h2 < kk) { cum += h2; b = 1; if (cum + h1 < kk) { cum += h1; b = 0; } } }
+                s_hist[256] = (unsigned)(4 * tid + b);
+                s_hist[257] = kk - cum;
+            }
+        }
+        __syncthreads();
+        prefix |= s_hist[256] << shift;
+        mask |= 255u << shift;
+        kk = s_hist[257];
+        __syncthreads();                            // (the two words are rewritten in the next pass)
+    }
+    return prefix;
+}
+
+__device__ __forceinline__ unsigned kth_largest_ord(const unsigned long long* keys, int M, int k, int tid, unsigned* s_hist) {
+    return kth_largest_of([&](int x) { return (unsigned)(keys[x] >> 32); }, M, k, tid, s_hist);
+}
+
+// The k-th largest 64-bit KEY among keys[0 .. M) (keys are unique: score ordinal << 32 | ~row id), k <= M: the k-th largest
+// high word, then -- inside its tie group -- the low word that completes the count.  Exactly k keys lie at or above the
+// result.  Whole workgroup; s_cnt: one shared word.
+__device__ __forceinline__ unsigned long long kth_largest_key(const unsigned long long* keys, int M, int k, int tid, unsigned* s_hist,
+                                                              unsigned* s_cnt) {
+    const unsigned sk = kth_largest_of([&](int x) { return (unsigned)(keys[x] >> 32); }, M, k, tid, s_hist);
+    if (tid == 0) *s_cnt = 0u;
+    __syncthreads();
+    unsigned gt = 0u;
+    for (int x = tid; x < M; x += SORT_THREADS) gt += (unsigned)(keys[x] >> 32) > sk ? 1u : 0u;
+    if (gt) atomicAdd(s_cnt, gt);
+    __syncthreads();
+    const int need_eq = k - (int)*s_cnt;                                // >= 1: the k-th itself has ordinal sk
+    __syncthreads();
+    const unsigned lowk = kth_largest_of([&](int x) { const unsigned long long kx = keys[x]; return (unsigned)(kx >> 32) == sk ? (unsigned)kx : 0u; },
+                                         M, need_eq, tid, s_hist);
+    return ((unsigned long long)sk << 32) | lowk;
+}
+
 // ------------------------------------------------------------------------------------------
 // One workgroup per query: bitonic sort (descending) of the candidate keys in LDS.
 __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A, int cap_pow2) {
@@ -459,6 +526,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
     __shared__ double s_kth;
     __shared__ double s_q2[SORT_THREADS / 64];
     __shared__ float s_amax[SORT_THREADS / 64];
+    __shared__ unsigned s_hist[260];
+    __shared__ unsigned s_cnt;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int rb = A.d * (A.dtype == DT_F32 ? 4 : 2);
     const int K2 = A.K2, k = A.k;
@@ -473,9 +542,32 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_sort(const SelectArgs A
         reinterpret_cast<f32x4*>(qrow)[i] = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(A.Q) + (size_t)q * rb)[i];
     if (tid == 0) { s_nvalid = 0; s_kth = 0.0; }
     __syncthreads();
-    for (int kk = 2; kk <= M2; kk <<= 1) {
+    // Only the K2 best candidates are needed, in order: with many more than that (the lists of a k = 500 search hold up to
+    // 2048), they are SELECTED first (kth_largest_key) and only they are sorted -- 45 barrier stages over 512 keys instead of
+    // 66 over 2048.  (The re-score slots serve as the compaction buffer: nothing has been re-scored yet.)
+    int Ms = M2;
+    {
+        int K2p = 64;
+        while (K2p < K2) K2p <<= 1;
+        if (M > 2 * K2p) {
+            const unsigned long long T = kth_largest_key(keys, M, K2, tid, s_hist, &s_cnt);
+            unsigned long long* tmp = reinterpret_cast<unsigned long long*>(resc);
+            __syncthreads();
+            if (tid == 0) s_cnt = 0u;
+            __syncthreads();
+            for (int x = tid; x < M; x += SORT_THREADS) {
+                const unsigned long long kx = keys[x];
+                if (kx >= T) tmp[atomicAdd(&s_cnt, 1u)] = kx;
+            }
+            __syncthreads();
+            for (int x = tid; x < K2p; x += SORT_THREADS) keys[x] = x < K2 ? tmp[x] : 0ull;
+            __syncthreads();
+            Ms = K2p;
+        }
+    }
+    for (int kk = 2; kk <= Ms; kk <<= 1) {
         for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < M2; i += SORT_THREADS) {
+            for (int i = tid; i < Ms; i += SORT_THREADS) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const unsigned long long a = keys[i], b = keys[ixj];
@@ -655,54 +747,6 @@ __device__ __forceinline__ void sort_desc(unsigned long long* keys, int M2, int 
     }
 }
 
-// The k-th largest score ordinal (high word of the keys) among keys[0 .. M), k <= M, by the whole workgroup of
-// SORT_THREADS = 256 threads: a radix descent, eight bits a pass -- a 256-bin histogram (LDS atomics) of the keys
-// that still match the prefix, then the bin holding the k-th from the top (one wave: four bins a lane, a suffix
-// sum by shuffles) -- four passes over the keys instead of a sort of up to 8192 of them (round 3; it was 32 one-bit
-// passes, 3 barriers each).  s_hist: 260 shared words; every thread returns the same value.
-template <typename OrdAt>
-__device__ __forceinline__ unsigned kth_largest_of(OrdAt ord_at, int M, int k, int tid, unsigned* s_hist) {
-    unsigned prefix = 0u, mask = 0u;
-    unsigned kk = (unsigned)k;                      // rank, from the top, inside the bucket that matches the prefix
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        s_hist[tid] = 0u;
-        __syncthreads();
-        for (int x = tid; x < M; x += SORT_THREADS) {
-            const unsigned o = ord_at(x);
-            if ((o & mask) == prefix) atomicAdd(&s_hist[(o >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const unsigned h0 = s_hist[4 * tid], h1 = s_hist[4 * tid + 1], h2 = s_hist[4 * tid + 2], h3 = s_hist[4 * tid + 3];
-            const unsigned mine = h0 + h1 + h2 + h3;
-            unsigned suf = mine;                    // sum over this lane and every higher one
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned v = (unsigned)__shfl_down((int)suf, o);
-                if (tid + o < 64) suf += v;
-            }
-            const unsigned above = suf - mine;
-            if (above < kk && suf >= kk) {          // the k-th from the top falls into this lane's four bins (exactly one lane)
-                unsigned cum = above;
-                int b = 3;
-                if (cum + h3 < kk) { cum += h3; b = 2; if (cum + h2 < kk) { cum += h2; b = 1; if (cum + h1 < kk) { cum += h1; b = 0; } } }
-                s_hist[256] = (unsigned)(4 * tid + b);
-                s_hist[257] = kk - cum;
-            }
-        }
-        __syncthreads();
-        prefix |= s_hist[256] << shift;
-        mask |= 255u << shift;
-        kk = s_hist[257];
-        __syncthreads();                            // (the two words are rewritten in the next pass)
-    }
-    return prefix;
-}
-
-__device__ __forceinline__ unsigned kth_largest_ord(const unsigned long long* keys, int M, int k, int tid, unsigned* s_hist) {
-    return kth_largest_of([&](int x) { return (unsigned)(keys[x] >> 32); }, M, k, tid, s_hist);
-}
-
 // k_bound_prepare (sss_ip_topk_long, between two levels; scan.h: launch_bound_prepare): no row is read.  At least k of
 // the kept rows have a scan score >= the k-th largest kept scan score s_k, so at least k rows have an exact score
 // >= s_k * unscale - B: a valid LOWER BOUND of the query's true k-th score, written to column k-1 of its row of D_out
@@ -865,18 +909,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_select_all(const ThrArgs A, in
     while (Ks < k) Ks <<= 1;
     const unsigned long long* outk = keys;
     if (keep > 2 * Ks) {
-        const unsigned sk = kth_largest_of([&](int x) { return (unsigned)(keys[x] >> 32); }, keep, k, tid, s_hist);
-        if (tid == 0) s_keep = 0u;
+        const unsigned long long T = kth_largest_key(keys, keep, k, tid, s_hist, &s_keep);
         __syncthreads();
-        unsigned gt = 0u;
-        for (int x = tid; x < keep; x += SORT_THREADS) gt += (unsigned)(keys[x] >> 32) > sk ? 1u : 0u;
-        if (gt) atomicAdd(&s_keep, gt);
-        __syncthreads();
-        const int need_eq = k - (int)s_keep;                            // >= 1: the k-th itself has ordinal sk
-        __syncthreads();
-        const unsigned lowk = kth_largest_of([&](int x) { const unsigned long long kx = keys[x]; return (unsigned)(kx >> 32) == sk ? (unsigned)kx : 0u; },
-                                             keep, need_eq, tid, s_hist);
-        const unsigned long long T = ((unsigned long long)sk << 32) | lowk;
         if (tid == 0) s_keep = 0u;
         __syncthreads();
         for (int x = tid; x < keep; x += SORT_THREADS) {                // (surv: the survivors' scan keys are no longer needed)
@@ -952,7 +986,7 @@ int launch_select(const SelectArgs& a, hipStream_t st) {
     static bool done2[MAX_DEVICES] = {};
     if (!done2[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_select_sort),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);     // (its static words take ~1.1 KB)
         done2[dev] = true;
     }
     hipLaunchKernelGGL(k_select_sort, dim3((unsigned)a.nq), dim3(SORT_THREADS), lds, st, a, cap_pow2);
