@@ -328,31 +328,54 @@ __global__ __launch_bounds__(RS_THREADS) void k_head_threshold(const float* __re
     const float* s = scores + (size_t)f * n;
     const long head = n < CP_HEAD ? n : CP_HEAD;         // sample size; rows i * stride: an evenly spread sample
     const long stride = n / head;                        // (corpora are often ordered -- by session length, by prefix ...)
-    // the sample is fetched ONCE (every element its own cache line: with the four passes reading global memory this
-    // single workgroup spent 0.40 ms per query on 262 k scattered loads at 4M rows)
-    for (long i = tid; i < head; i += RS_THREADS) {
-        const float v = s[i * stride];
-        ords[i] = f2ord(metric == 0 ? v : -v);
-    }
+    // The sample is fetched ONCE (every element its own cache line: with the four passes reading global memory this single
+    // workgroup spent 0.40 ms per query on 262 k scattered loads at 4M rows).  k <= 1024 (always, on the paths that reach
+    // this kernel today): a thread keeps only the MAXIMUM of its 32 samples -- 1024 distinct rows, so their k-th largest is
+    // still a value that k rows reach -- and the radix passes run over 1024 words instead of 32768 (the first pass of the
+    // full form put all 32768 LDS atomics on two or three bins: 0.23 ms per query even from LDS).  The bound is a little
+    // looser (about the top 2 % of the corpus survive the compaction instead of 1.5 %).
     unsigned need = (unsigned)((long)k < head ? k : head), prefix = 0, mask = 0;
+    long cnt = head;
+    if (need <= RS_THREADS && head >= RS_THREADS) {
+        unsigned best = 0u;
+        for (long i = tid; i < head; i += RS_THREADS) {
+            const float v = s[i * stride];
+            best = max(best, f2ord(metric == 0 ? v : -v));
+        }
+        ords[tid] = best;
+        cnt = RS_THREADS;
+    } else {
+        for (long i = tid; i < head; i += RS_THREADS) {
+            const float v = s[i * stride];
+            ords[i] = f2ord(metric == 0 ? v : -v);
+        }
+    }
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         for (int i = tid; i < 256; i += RS_THREADS) hist[i] = 0;
         __syncthreads();
-        for (long i = tid; i < head; i += RS_THREADS) {
+        for (long i = tid; i < cnt; i += RS_THREADS) {
             const unsigned key = ords[i];
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned cum = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (cum + hist[b] >= need) break;
-                cum += hist[b];
+        if (tid < 64) {                                  // the bin holding the need-th key from the top: four bins a lane, suffix sum by shuffles
+            const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const unsigned mine = h0 + h1 + h2 + h3;
+            unsigned suf = mine;                         // sum over this lane and every higher one
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = (unsigned)__shfl_down((int)suf, o);
+                if (tid + o < 64) suf += v;
             }
-            s_prefix = prefix | ((unsigned)b << shift);
-            s_need = need - cum;
+            const unsigned above = suf - mine;
+            if (above < need && suf >= need) {           // (exactly one lane)
+                unsigned cum = above;
+                int b2 = 3;
+                if (cum + h3 < need) { cum += h3; b2 = 2; if (cum + h2 < need) { cum += h2; b2 = 1; if (cum + h1 < need) { cum += h1; b2 = 0; } } }
+                s_prefix = prefix | ((unsigned)(4 * tid + b2) << shift);
+                s_need = need - cum;
+            }
         }
         __syncthreads();
         prefix = s_prefix; need = s_need;
